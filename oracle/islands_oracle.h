@@ -1,0 +1,203 @@
+/*
+ * islands_oracle.h -- CPU restatement of the islands `core` search hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke()
+ * entry and bench.py's cpu_baseline leg may link or call it; the product
+ * path (islands_amd/csrc, libislands_amd.so) never does.
+ *
+ * The reference (panbanda/islands v1.5.0) is Rust and no Rust toolchain
+ * exists in the build image, so every function here is a restatement written
+ * from the source text.  Each function cites the reference file:line it
+ * follows.  All f32 arithmetic keeps the reference's operation order
+ * (strict left-to-right scalar accumulation, separate multiply and add
+ * roundings): build with -O2 -ffp-contract=off and never -ffast-math.
+ *
+ * Pinning status:
+ *   - distance metrics, PQ helpers, CSR accessors, to_similarity: pinned by
+ *     the reference's own known-answer tests (restated in tests/).
+ *   - search / build neighbour lists: the reference holds no golden vectors
+ *     and cannot be run here -> PARITY UNPINNED beyond the reference's
+ *     property tests (self-query, ordering, counts, recall gate).
+ *   - bincode byte layout: PARITY UNPINNED (reference tests only round-trip).
+ *
+ * [external] semantics restated from published behaviour, not from the tree:
+ *   Rust std::collections::BinaryHeap (push = append + sift_up; pop = swap
+ *   last into root, sift_down_to_bottom, sift_up; into_iter = backing-array
+ *   order), slice::sort_by (stable), ordered_float 5.x total order (NaN
+ *   greatest, -0 == +0), f32 Iterator::sum (left fold from 0.0),
+ *   bincode 1.x default options (little-endian, fixed-width ints).
+ */
+#ifndef ISLANDS_ORACLE_H
+#define ISLANDS_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* CoreError variants, src/core/error.rs:9-62, in declaration order (0 = Ok). */
+enum {
+  ORC_OK = 0,
+  ORC_DIMENSION_MISMATCH = 1,
+  ORC_EMPTY_COLLECTION = 2,
+  ORC_INVALID_CONFIG = 3,
+  ORC_INDEX_NOT_BUILT = 4,
+  ORC_NODE_NOT_FOUND = 5,
+  ORC_SERIALIZATION = 6,
+  ORC_DESERIALIZATION = 7,
+  ORC_IO = 8,
+  ORC_HNSW_ERROR = 9,
+  ORC_PQ_ERROR = 10,
+  ORC_SEARCH_ERROR = 11,
+  ORC_EMBEDDING_ERROR = 12,
+  ORC_PANIC = 99 /* the reference would panic (e.g. unwrap on NaN compare) */
+};
+
+/* DistanceMetric, src/core/distance.rs:9-19 (variant order). */
+enum { ORC_COSINE = 0, ORC_EUCLIDEAN = 1, ORC_DOT = 2, ORC_MANHATTAN = 3 };
+
+/* PruningStrategy, src/core/leann.rs:168-178. */
+enum { ORC_PRUNE_GLOBAL = 0, ORC_PRUNE_LOCAL = 1, ORC_PRUNE_PROPORTIONAL = 2 };
+
+/* ---- distance.rs ---- */
+int orc_distance(int metric, const float* a, size_t na, const float* b, size_t nb, float* out);
+int orc_distance_squared(int metric, const float* a, size_t na, const float* b, size_t nb,
+                         float* out);
+/* rows: n contiguous rows of length d (row-major). distance.rs:32-34 */
+int orc_batch_distance(int metric, const float* q, size_t d, const float* rows, size_t n,
+                       float* out);
+void orc_normalize(float* v, size_t d); /* distance.rs:125-132 */
+
+/* ---- leann.rs: CSR graph view ---- */
+typedef struct {
+  uint64_t num_nodes;
+  const uint64_t* node_offsets; /* num_nodes + 1 */
+  const uint64_t* neighbors;
+  const uint64_t* degree_counts; /* may be NULL (only Proportional pruning reads it) */
+  int has_entry;
+  uint64_t entry_point;
+} orc_csr;
+
+/* CsrGraph::get_neighbors, leann.rs:225-233.  Returns 0 and sets len and ptr, or -1 for None. */
+int orc_csr_get_neighbors(const orc_csr* g, uint64_t node, const uint64_t** ptr, size_t* len);
+
+typedef struct {
+  int metric;
+  float prune_ratio;
+  int pruning_strategy;
+  int has_dimension; /* LeannIndex.dimension: Option<usize> */
+  uint64_t dimension;
+} orc_leann_params;
+
+/* Per-query counters: H expansions, E neighbour ids read,
+ * V embeddings computed / distances evaluated (incl. the entry), P pushes. */
+typedef struct {
+  uint64_t expansions, edges, evals, pushes;
+} orc_counters;
+
+/* In-memory provider: `vectors` is nvec rows of `d` floats (leann.rs:104-159).
+ * copy_per_node != 0 reproduces the provider's Vec clone (malloc+memcpy) per
+ * node, as InMemoryEmbeddingProvider does (leann.rs:145-154); 0 = zero-copy.
+ *
+ * LeannIndex::search_with_params, leann.rs:868-896 (+ search_layer_recompute
+ * :899-988, apply_pruning_strategy :991-1016).  out_ids/out_dist hold k slots;
+ * *out_count <= k.  *err_payload gets the NodeNotFound id / actual dimension. */
+int orc_leann_search(const orc_csr* g, const orc_leann_params* p, const float* vectors,
+                     uint64_t nvec, size_t d, int copy_per_node, const float* query, size_t qd,
+                     size_t k, size_t ef, uint64_t* out_ids, float* out_dist, size_t* out_count,
+                     orc_counters* ctr, uint64_t* err_payload);
+
+/* Same search but returns the WHOLE sorted result vector of search_layer_recompute
+ * (up to ef entries), for white-box tests. out arrays hold ef slots. */
+int orc_leann_search_layer(const orc_csr* g, const orc_leann_params* p, const float* vectors,
+                           uint64_t nvec, size_t d, const float* query, uint64_t entry, size_t ef,
+                           uint64_t* out_ids, float* out_dist, size_t* out_count,
+                           orc_counters* ctr, uint64_t* err_payload);
+
+/* LeannIndex::build, leann.rs:560-631 (+ :634-833).  `levels[i]` replaces
+ * random_level() (thread_rng, leann.rs:549-554), the only non-determinism.
+ * Output CSR arrays are malloc'ed; free with orc_free. */
+typedef struct {
+  uint64_t m, m0, ef_construction;
+  int metric;
+  int high_degree_pruning;
+  float hub_percentile;
+} orc_build_params;
+
+typedef struct {
+  uint64_t num_nodes;
+  uint64_t* node_offsets;
+  uint64_t* neighbors;
+  uint64_t* degree_counts;
+  uint64_t* levels;
+  int has_entry;
+  uint64_t entry_point;
+  uint64_t max_level;
+} orc_csr_owned;
+
+int orc_leann_build(const float* vectors, uint64_t n, size_t d, const orc_build_params* bp,
+                    const uint64_t* levels, orc_csr_owned* out);
+void orc_csr_free(orc_csr_owned* g);
+void orc_free(void* p);
+
+/* ---- hnsw.rs ---- */
+typedef struct orc_hnsw orc_hnsw;
+orc_hnsw* orc_hnsw_new(uint64_t m, uint64_t m0, uint64_t ef_construction, int metric);
+void orc_hnsw_free(orc_hnsw* h);
+/* HnswGraph::insert, hnsw.rs:214-329; `level` replaces random_level(). */
+int orc_hnsw_insert(orc_hnsw* h, const float* v, size_t d, uint64_t level, uint64_t* out_id);
+/* HnswGraph::search, hnsw.rs:458-504. */
+int orc_hnsw_search(const orc_hnsw* h, const float* q, size_t qd, size_t k, size_t ef,
+                    uint64_t* out_ids, float* out_dist, size_t* out_count, orc_counters* ctr);
+uint64_t orc_hnsw_len(const orc_hnsw* h);
+uint64_t orc_hnsw_max_level(const orc_hnsw* h);
+int orc_hnsw_entry(const orc_hnsw* h, uint64_t* entry);
+/* Layer adjacency of one node (for exporting to the device format). */
+int orc_hnsw_neighbors(const orc_hnsw* h, uint64_t node, uint64_t layer, const uint64_t** ptr,
+                       size_t* len);
+uint64_t orc_hnsw_level(const orc_hnsw* h, uint64_t node);
+const float* orc_hnsw_vector(const orc_hnsw* h, uint64_t node);
+
+/* ---- search.rs ---- */
+float orc_to_similarity(float score); /* search.rs:100-102 */
+/* MultiIndexSearcher::search merge, search.rs:211-237: lists concatenated in
+ * index order, stable sort by score ascending, truncate(top_k).
+ * list_ids/list_scores: nlists pointers, list_len[i] entries each.
+ * out_src receives the index (shard) each result came from. */
+int orc_multi_index_merge(size_t nlists, const uint64_t* const* list_ids,
+                          const float* const* list_scores, const size_t* list_len, size_t top_k,
+                          uint64_t* out_ids, float* out_scores, uint32_t* out_src,
+                          size_t* out_count);
+/* Product merge, src/indexer/service.rs:787-801: score = 1 - distance, sort
+ * descending by score (partial_cmp, NaN -> Equal), truncate(top_k). */
+int orc_service_merge(size_t nlists, const uint64_t* const* list_ids,
+                      const float* const* list_dist, const size_t* list_len, size_t top_k,
+                      uint64_t* out_ids, float* out_scores, uint32_t* out_src, size_t* out_count);
+
+/* ---- pq.rs ---- */
+/* Codebooks: m subquantizers x K centroids x dsub floats, contiguous. */
+int orc_pq_find_nearest(int metric, const float* centroids, size_t K, size_t dsub,
+                        const float* sub, size_t sublen, uint64_t* out); /* pq.rs:86-106 */
+int orc_pq_encode(int metric, const float* codebooks, size_t m, size_t K, size_t dsub,
+                  const float* v, size_t d, uint16_t* codes); /* pq.rs:221-244 */
+int orc_pq_decode(const float* codebooks, size_t m, size_t K, size_t dsub, const uint16_t* codes,
+                  size_t ncodes, float* out); /* pq.rs:247-271 */
+int orc_pq_asymmetric_distance(const float* codebooks, size_t m, size_t K, size_t dsub,
+                               const float* q, size_t d, const uint16_t* codes, size_t ncodes,
+                               float* out); /* pq.rs:275-304 */
+int orc_pq_build_tables(const float* codebooks, size_t m, size_t K, size_t dsub, const float* q,
+                        size_t d, float* tables /* m*K */); /* pq.rs:307-338 */
+float orc_pq_table_distance(const float* tables, size_t m, size_t K,
+                            const uint16_t* codes); /* pq.rs:341-348 */
+
+/* ---- embedding/candle_provider.rs:434-488: masked mean-pool + L2 normalise ----
+ * hidden: [B][L][H] f32, mask: [B][L] (0/1 as f32). out: [B][H]. */
+void orc_mean_pool_normalize(const float* hidden, const float* mask, size_t B, size_t L, size_t H,
+                             int normalize, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
