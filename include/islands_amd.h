@@ -1,0 +1,234 @@
+/*
+ * islands_amd.h -- C ABI of the MI355X-native LEANN search path.
+ *
+ * This is the drop-in boundary for the `islands::core` search hot path of
+ * panbanda/islands v1.5.0.  The reference has no FFI of its own (it is a
+ * single Rust crate); each entry point below replaces one inherent method /
+ * trait method of `src/core`, cited as file:line, and is what a Rust
+ * `unsafe extern "C"` block would bind (see INTEGRATION.md for that stub).
+ *
+ * Conventions
+ *   - every function returns isl_status (0 = Ok, otherwise the CoreError
+ *     variant of src/core/error.rs:9-62, same order); nothing aborts or throws
+ *     across the ABI.  Details of the last error on the calling thread are read
+ *     with the isl_last_error_* getters.
+ *   - inputs are borrowed for the duration of the call; outputs are written
+ *     into caller-allocated buffers, except *_to_bytes (freed with
+ *     isl_free_bytes).  An index handle owns its host and device copies.
+ *   - plain pointers and sizes only; no C++/torch types.  `stream` arguments
+ *     are a hipStream_t passed as void* (NULL = the library's own stream).
+ *   - the compute path is HIP on gfx950.  There is NO CPU fallback: without a
+ *     usable device every compute entry point returns ISL_ERR_DEVICE.
+ */
+#ifndef ISLANDS_AMD_H
+#define ISLANDS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISL_ABI_VERSION 1
+
+typedef int32_t isl_status;
+
+/* CoreError, src/core/error.rs:9-62 (declaration order), plus ABI-level codes >= 100. */
+enum {
+  ISL_OK = 0,
+  ISL_ERR_DIMENSION_MISMATCH = 1, /* payload: expected, actual */
+  ISL_ERR_EMPTY_COLLECTION = 2,
+  ISL_ERR_INVALID_CONFIG = 3,
+  ISL_ERR_INDEX_NOT_BUILT = 4,
+  ISL_ERR_NODE_NOT_FOUND = 5, /* payload: node id */
+  ISL_ERR_SERIALIZATION = 6,
+  ISL_ERR_DESERIALIZATION = 7,
+  ISL_ERR_IO = 8,
+  ISL_ERR_HNSW = 9,
+  ISL_ERR_PQ = 10,
+  ISL_ERR_SEARCH = 11,
+  ISL_ERR_EMBEDDING = 12,
+  ISL_ERR_DEVICE = 100,           /* no gfx950 device / HIP runtime error */
+  ISL_ERR_INVALID_ARGUMENT = 101, /* NULL pointer, bad enum value */
+  ISL_ERR_UNSUPPORTED = 102
+};
+
+/* DistanceMetric, src/core/distance.rs:9-19 (bincode variant index). */
+enum { ISL_METRIC_COSINE = 0, ISL_METRIC_EUCLIDEAN = 1, ISL_METRIC_DOT = 2, ISL_METRIC_MANHATTAN = 3 };
+/* PruningStrategy, src/core/leann.rs:168-178. */
+enum { ISL_PRUNE_GLOBAL = 0, ISL_PRUNE_LOCAL = 1, ISL_PRUNE_PROPORTIONAL = 2 };
+/* Row element types accepted by isl_set_embeddings. */
+enum { ISL_DTYPE_F32 = 0, ISL_DTYPE_BF16 = 1 };
+/* Where a caller's buffer lives. */
+enum { ISL_MEM_HOST = 0, ISL_MEM_DEVICE = 1 };
+
+/* ---- error details (thread-local) ---- */
+const char* isl_last_error_message(void);
+uint64_t isl_last_error_expected(void); /* DimensionMismatch.expected */
+uint64_t isl_last_error_actual(void);   /* DimensionMismatch.actual   */
+uint64_t isl_last_error_node(void);     /* NodeNotFound(id)           */
+const char* isl_status_name(isl_status s);
+uint32_t isl_abi_version(void);
+/* Number of usable gfx950 devices (0 when none; never an error). */
+int32_t isl_device_count(void);
+
+/* ---- LeannConfig, src/core/leann.rs:322-371 (same fields, same order) ---- */
+typedef struct isl_leann_config {
+  uint64_t m;
+  uint64_t m0;
+  uint64_t ef_construction;
+  double ml;
+  uint64_t max_layers;
+  uint32_t metric; /* ISL_METRIC_* */
+  uint64_t ef_search;
+  uint64_t beam_width;
+  float prune_ratio;
+  uint32_t pruning_strategy; /* ISL_PRUNE_* */
+  uint8_t high_degree_pruning;
+  float hub_percentile;
+  uint8_t is_compact;
+  uint8_t is_recompute;
+} isl_leann_config;
+
+void isl_leann_config_paper_default(isl_leann_config* c); /* leann.rs:386-403 */
+void isl_leann_config_fast(isl_leann_config* c);          /* leann.rs:406-416 */
+void isl_leann_config_accurate(isl_leann_config* c);      /* leann.rs:419-429 */
+isl_status isl_leann_config_validate(const isl_leann_config* c); /* leann.rs:432-460 */
+
+/* ---- LeannIndex, src/core/leann.rs:492-546 ---- */
+typedef struct isl_index isl_index;
+
+/* LeannIndex::new, leann.rs:504-511 (validates the config). */
+isl_status isl_index_new(const isl_leann_config* cfg, isl_index** out);
+/* Build an index handle from CsrGraph's public fields (leann.rs:193-208).
+ * levels/degree_counts may be NULL (zeros / row lengths).  dimension:
+ * has_dimension = 0 encodes None. */
+isl_status isl_index_from_csr(const isl_leann_config* cfg, uint64_t num_nodes,
+                              const uint64_t* node_offsets, const uint64_t* neighbors,
+                              const uint64_t* levels, const uint64_t* degree_counts,
+                              int32_t has_entry, uint64_t entry_point, uint64_t max_level,
+                              int32_t has_dimension, uint64_t dimension, isl_index** out);
+/* Same, from arrays already resident on `device` (u64 offsets, u32 neighbour
+ * ids); the handle takes a private device copy, the host CSR is materialised
+ * lazily (to_bytes / get_neighbors). */
+isl_status isl_index_from_device_csr(const isl_leann_config* cfg, int32_t device,
+                                     uint64_t num_nodes, const uint64_t* d_node_offsets,
+                                     const uint32_t* d_neighbors, int32_t has_entry,
+                                     uint64_t entry_point, int32_t has_dimension,
+                                     uint64_t dimension, isl_index** out);
+/* LeannIndex::from_bytes / to_bytes, leann.rs:1059-1066 (bincode 1.x default layout). */
+isl_status isl_index_from_bytes(const uint8_t* bytes, size_t len, isl_index** out);
+isl_status isl_index_to_bytes(const isl_index* idx, uint8_t** out, size_t* len);
+void isl_free_bytes(uint8_t* p);
+void isl_index_free(isl_index* idx);
+
+uint64_t isl_index_len(const isl_index* idx);                 /* leann.rs:519-521 */
+int32_t isl_index_is_empty(const isl_index* idx);             /* leann.rs:524-526 */
+int32_t isl_index_dimension(const isl_index* idx, uint64_t* dim); /* 1 = Some, leann.rs:529 */
+uint64_t isl_index_storage_bytes(const isl_index* idx);       /* leann.rs:534, 296-301 */
+int32_t isl_index_is_recompute(const isl_index* idx);         /* leann.rs:539 */
+int32_t isl_index_is_compact(const isl_index* idx);           /* leann.rs:544 */
+isl_status isl_index_config(const isl_index* idx, isl_leann_config* out);
+int32_t isl_index_entry_point(const isl_index* idx, uint64_t* entry); /* 1 = Some */
+uint64_t isl_index_max_level(const isl_index* idx);
+/* CsrGraph::get_neighbors, leann.rs:225-233: returns 1 (Some) / 0 (None).  The
+ * slice stays valid until the index is freed. */
+int32_t isl_index_get_neighbors(const isl_index* idx, uint64_t node, const uint64_t** ptr,
+                                size_t* len);
+
+/* Copy the CSR graph into HBM of `device` (u64 offsets, u32 neighbour ids). */
+isl_status isl_index_upload(isl_index* idx, int32_t device);
+
+/* InMemoryEmbeddingProvider::new, leann.rs:111-120: attach n rows of d
+ * elements as the provider for this index.  `rows` is row-major, on the host
+ * or already on the index's device (mem = ISL_MEM_*).  The handle keeps its
+ * own HBM copy (rows padded to 16-byte multiples).  n == 0 -> EmptyCollection. */
+isl_status isl_set_embeddings(isl_index* idx, const void* rows, uint64_t n, uint64_t d,
+                              int32_t dtype, int32_t mem);
+
+/* ---- search ---- */
+/* LeannIndex::search_with_params over a batch of queries (leann.rs:868-896;
+ * batch = Searcher::search_batch semantics, search.rs:179-181: each query is
+ * answered independently, results in query order).
+ *   queries: nq rows of d floats; out_ids/out_dist: nq*k slots, row i holds
+ *   out_count[i] <= k valid entries, ascending distance.
+ * Errors that the reference raises per query (NodeNotFound) fail the whole
+ * call with the first failing query's error, as the sequential map would. */
+isl_status isl_search_batch(const isl_index* idx, const float* queries, uint64_t nq, uint64_t d,
+                            uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dist,
+                            uint32_t* out_count);
+/* Same with every buffer already on the index's device; enqueued on `stream`
+ * and synchronised before returning (status needs the result). */
+isl_status isl_search_batch_device(const isl_index* idx, const float* d_queries, uint64_t nq,
+                                   uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_out_ids,
+                                   float* d_out_dist, uint32_t* d_out_count, void* stream);
+/* LeannIndex::search, leann.rs:858-865: one query, ef = config.ef_search. */
+isl_status isl_search(const isl_index* idx, const float* query, uint64_t d, uint64_t k,
+                      uint64_t* out_ids, float* out_dist, uint32_t* out_count);
+
+/* Work counters of the most recent search call on this index (summed over the
+ * batch): the inputs of the roofline formula. */
+typedef struct isl_search_stats {
+  uint64_t queries;
+  uint64_t expansions;     /* H: candidates expanded */
+  uint64_t edges;          /* E: neighbour ids read */
+  uint64_t evals;          /* V: embeddings fetched / distances evaluated */
+  uint64_t pushes;         /* heap insertions */
+  uint64_t exact_path;     /* queries answered by the heap-exact kernel */
+  double kernel_ms;        /* HIP-event time of the search kernels of that call */
+} isl_search_stats;
+isl_status isl_search_last_stats(const isl_index* idx, isl_search_stats* out);
+
+/* ---- distance.rs ---- */
+/* Distance::calculate, distance.rs:38-52. */
+isl_status isl_distance(int32_t metric, const float* a, uint64_t na, const float* b, uint64_t nb,
+                        float* out);
+/* Distance::calculate_squared, distance.rs:54-66. */
+isl_status isl_distance_squared(int32_t metric, const float* a, uint64_t na, const float* b,
+                                uint64_t nb, float* out);
+/* Distance::batch_calculate, distance.rs:32-34: query against n contiguous
+ * rows of `row_len` floats (row_len != d -> DimensionMismatch). mem applies
+ * to query, rows and out alike. */
+isl_status isl_distance_batch(int32_t metric, const float* query, uint64_t d, const float* rows,
+                              uint64_t n, uint64_t row_len, float* out, int32_t mem, int32_t device,
+                              void* stream);
+/* normalize_vector, distance.rs:125-132, over n rows in place. */
+isl_status isl_normalize_rows(float* rows, uint64_t n, uint64_t d, int32_t mem, int32_t device,
+                              void* stream);
+
+/* ---- search.rs / indexer merge (multi-index = multi-shard) ---- */
+/* MultiIndexSearcher::search merge, search.rs:211-237: per query, nlists
+ * candidate lists (list-major: [list][query][k]) concatenated in list order,
+ * stable-sorted by score ascending, truncated to top_k.  id_base[l] is added to
+ * list l's ids (global id = shard base + local id).  counts: [list][query]. */
+isl_status isl_merge_topk(uint64_t nlists, uint64_t nq, uint64_t k, const uint64_t* ids,
+                          const float* scores, const uint32_t* counts, const uint64_t* id_base,
+                          uint64_t top_k, uint64_t* out_ids, float* out_scores,
+                          uint32_t* out_src, uint32_t* out_count, int32_t mem, int32_t device,
+                          void* stream);
+
+/* ---- pq.rs ---- */
+typedef struct isl_pq isl_pq;
+/* ProductQuantizer with trained codebooks: m x K x dsub floats (pq.rs:116-129). */
+isl_status isl_pq_new(uint64_t dimension, uint64_t m, uint64_t K, const float* codebooks,
+                      int32_t metric, int32_t device, isl_pq** out);
+void isl_pq_free(isl_pq* pq);
+/* build_distance_tables, pq.rs:307-338, for nq queries: tables [nq][m][K]. */
+isl_status isl_pq_build_distance_tables(const isl_pq* pq, const float* queries, uint64_t nq,
+                                        uint64_t d, float* tables, int32_t mem, void* stream);
+/* table_distance, pq.rs:341-348: codes [n][m] u16 against ONE query's tables [m][K]. */
+isl_status isl_pq_table_distance(const isl_pq* pq, const float* tables, const uint16_t* codes,
+                                 uint64_t n, float* out, int32_t mem, void* stream);
+/* asymmetric_distance, pq.rs:275-304: one query against n code rows. */
+isl_status isl_pq_asymmetric_distance(const isl_pq* pq, const float* query, uint64_t d,
+                                      const uint16_t* codes, uint64_t n, float* out, int32_t mem,
+                                      void* stream);
+/* encode, pq.rs:221-244: n vectors -> [n][m] u16 codes. */
+isl_status isl_pq_encode(const isl_pq* pq, const float* vectors, uint64_t n, uint64_t d,
+                         uint16_t* codes, int32_t mem, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISLANDS_AMD_H */

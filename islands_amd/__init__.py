@@ -1,0 +1,497 @@
+"""islands_amd -- host-side mirror of `islands::core` for the MI355X LEANN search path.
+
+Same names and argument meaning as the reference's re-exports
+(src/core/mod.rs:60-99): DistanceMetric, LeannConfig, LeannIndex, CsrGraph,
+InMemoryEmbeddingProvider, PruningStrategy, ProductQuantizer, CoreError.
+Every compute call goes through the C ABI of libislands_amd.so (HIP kernels
+for gfx950); there is no CPU implementation in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import LeannConfigC, SearchStatsC
+
+__all__ = [
+    "CoreError", "DistanceMetric", "PruningStrategy", "LeannConfig", "CsrGraph",
+    "InMemoryEmbeddingProvider", "LeannIndex", "ProductQuantizer", "SearchResult",
+    "batch_calculate", "calculate", "calculate_squared", "normalize_rows", "merge_topk",
+    "device_count",
+]
+
+MEM_HOST, MEM_DEVICE = 0, 1
+
+
+class CoreError(Exception):
+    """CoreError, src/core/error.rs:9-62.  `kind` is the variant name."""
+
+    def __init__(self, status: int, message: str, expected=0, actual=0, node=0):
+        super().__init__(message)
+        self.status = status
+        self.kind = _ffi.lib().isl_status_name(status).decode()
+        self.expected, self.actual, self.node = expected, actual, node
+
+
+def _check(status: int):
+    if status != 0:
+        l = _ffi.lib()
+        raise CoreError(status, l.isl_last_error_message().decode(), l.isl_last_error_expected(),
+                        l.isl_last_error_actual(), l.isl_last_error_node())
+
+
+def device_count() -> int:
+    return int(_ffi.lib().isl_device_count())
+
+
+class DistanceMetric(enum.IntEnum):
+    """src/core/distance.rs:9-19"""
+    Cosine = 0
+    Euclidean = 1
+    DotProduct = 2
+    Manhattan = 3
+
+
+class PruningStrategy(enum.IntEnum):
+    """src/core/leann.rs:168-178"""
+    Global = 0
+    Local = 1
+    Proportional = 2
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# --------------------------------------------------------------- distance.rs
+def calculate(metric: DistanceMetric, a, b) -> float:
+    """Distance::calculate, distance.rs:38-52."""
+    a, b = _f32(a).ravel(), _f32(b).ravel()
+    out = C.c_float()
+    _check(_ffi.lib().isl_distance(int(metric), _ptr(a), a.size, _ptr(b), b.size, C.byref(out)))
+    return out.value
+
+
+def calculate_squared(metric: DistanceMetric, a, b) -> float:
+    """Distance::calculate_squared, distance.rs:54-66."""
+    a, b = _f32(a).ravel(), _f32(b).ravel()
+    out = C.c_float()
+    _check(_ffi.lib().isl_distance_squared(int(metric), _ptr(a), a.size, _ptr(b), b.size,
+                                           C.byref(out)))
+    return out.value
+
+
+def batch_calculate(metric: DistanceMetric, query, vectors, device: int = 0) -> np.ndarray:
+    """Distance::batch_calculate, distance.rs:32-34 (vectors: n rows)."""
+    q = _f32(query).ravel()
+    v = _f32(vectors)
+    if v.ndim != 2:
+        v = v.reshape(0, q.size) if v.size == 0 else v.reshape(1, -1)
+    n, row_len = v.shape
+    out = np.empty(n, dtype=np.float32)
+    _check(_ffi.lib().isl_distance_batch(int(metric), _ptr(q), q.size, _ptr(v), n, row_len,
+                                         _ptr(out), MEM_HOST, device, None))
+    return out
+
+
+def normalize_rows(rows, device: int = 0) -> np.ndarray:
+    """normalize_vector (distance.rs:125-132) applied to every row; returns a copy."""
+    r = _f32(rows).copy()
+    if r.ndim == 1:
+        r = r.reshape(1, -1)
+    _check(_ffi.lib().isl_normalize_rows(_ptr(r), r.shape[0], r.shape[1], MEM_HOST, device, None))
+    return r
+
+
+# ------------------------------------------------------------------ leann.rs
+@dataclass
+class LeannConfig:
+    """src/core/leann.rs:322-371; defaults = paper_default() (leann.rs:386-403)."""
+    m: int = 30
+    m0: int = 60
+    ef_construction: int = 128
+    ml: float = 1.0 / float(np.log(30.0))
+    max_layers: int = 16
+    metric: DistanceMetric = DistanceMetric.Cosine
+    ef_search: int = 64
+    beam_width: int = 1
+    prune_ratio: float = 0.0
+    pruning_strategy: PruningStrategy = PruningStrategy.Global
+    high_degree_pruning: bool = True
+    hub_percentile: float = 0.02
+    is_compact: bool = True
+    is_recompute: bool = True
+
+    @classmethod
+    def _from_c(cls, c: LeannConfigC) -> "LeannConfig":
+        return cls(c.m, c.m0, c.ef_construction, c.ml, c.max_layers, DistanceMetric(c.metric),
+                   c.ef_search, c.beam_width, c.prune_ratio, PruningStrategy(c.pruning_strategy),
+                   bool(c.high_degree_pruning), c.hub_percentile, bool(c.is_compact),
+                   bool(c.is_recompute))
+
+    def _to_c(self) -> LeannConfigC:
+        return LeannConfigC(self.m, self.m0, self.ef_construction, self.ml, self.max_layers,
+                            int(self.metric), self.ef_search, self.beam_width, self.prune_ratio,
+                            int(self.pruning_strategy), int(self.high_degree_pruning),
+                            self.hub_percentile, int(self.is_compact), int(self.is_recompute))
+
+    @classmethod
+    def paper_default(cls) -> "LeannConfig":
+        c = LeannConfigC()
+        _ffi.lib().isl_leann_config_paper_default(C.byref(c))
+        return cls._from_c(c)
+
+    @classmethod
+    def fast(cls) -> "LeannConfig":
+        c = LeannConfigC()
+        _ffi.lib().isl_leann_config_fast(C.byref(c))
+        return cls._from_c(c)
+
+    @classmethod
+    def accurate(cls) -> "LeannConfig":
+        c = LeannConfigC()
+        _ffi.lib().isl_leann_config_accurate(C.byref(c))
+        return cls._from_c(c)
+
+    def validate(self) -> None:
+        c = self._to_c()
+        _check(_ffi.lib().isl_leann_config_validate(C.byref(c)))
+
+
+@dataclass
+class CsrGraph:
+    """CsrGraph's public fields, src/core/leann.rs:193-208."""
+    node_offsets: np.ndarray = field(default_factory=lambda: np.zeros(1, dtype=np.uint64))
+    neighbors: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.uint64))
+    levels: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.uint64))
+    entry_point: int | None = None
+    max_level: int = 0
+    num_nodes: int = 0
+    degree_counts: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.uint64))
+
+    def add_node(self, neighbors, level: int) -> int:
+        """leann.rs:236-253"""
+        nid = self.num_nodes
+        self.num_nodes += 1
+        nb = np.asarray(list(neighbors), dtype=np.uint64)
+        self.levels = np.append(self.levels, np.uint64(level))
+        self.degree_counts = np.append(self.degree_counts, np.uint64(nb.size))
+        self.neighbors = np.concatenate([self.neighbors.astype(np.uint64), nb])
+        self.node_offsets = np.append(self.node_offsets, np.uint64(self.neighbors.size))
+        if self.entry_point is None or level > self.max_level:
+            self.entry_point = nid
+            self.max_level = level
+        return nid
+
+    def get_neighbors(self, node_id: int):
+        """leann.rs:225-233"""
+        if node_id >= self.num_nodes:
+            return None
+        s, e = int(self.node_offsets[node_id]), int(self.node_offsets[node_id + 1])
+        return self.neighbors[s:e]
+
+    def storage_bytes(self) -> int:
+        """leann.rs:296-301"""
+        return 8 * (self.node_offsets.size + self.neighbors.size + self.levels.size +
+                    self.degree_counts.size)
+
+
+class InMemoryEmbeddingProvider:
+    """leann.rs:104-159: id -> row of a resident matrix."""
+
+    def __init__(self, embeddings):
+        e = _f32(embeddings)
+        if e.ndim != 2 or e.shape[0] == 0:
+            raise CoreError(2, "Empty vector collection")  # leann.rs:112-114
+        self.embeddings = e
+
+    def dimension(self) -> int:
+        return int(self.embeddings.shape[1])
+
+    def __len__(self):
+        return int(self.embeddings.shape[0])
+
+
+@dataclass
+class SearchResult:
+    """search.rs:54-103"""
+    id: int
+    score: float
+
+    def to_similarity(self) -> float:
+        return float(np.float32(1.0) / (np.float32(1.0) + np.float32(self.score)))
+
+
+class LeannIndex:
+    """LeannIndex, src/core/leann.rs:492-1067, backed by an isl_index handle."""
+
+    def __init__(self, config: LeannConfig | None = None, _handle=None):
+        self._h = C.c_void_p()
+        self._provider_key = None
+        if _handle is not None:
+            self._h = _handle
+            return
+        c = (config or LeannConfig())._to_c()
+        _check(_ffi.lib().isl_index_new(C.byref(c), C.byref(self._h)))  # leann.rs:504-511
+
+    @classmethod
+    def with_defaults(cls) -> "LeannIndex":
+        return cls(LeannConfig())
+
+    @classmethod
+    def from_csr(cls, graph: CsrGraph, config: LeannConfig | None = None,
+                 dimension: int | None = None) -> "LeannIndex":
+        cfg = (config or LeannConfig())._to_c()
+        off = np.ascontiguousarray(graph.node_offsets, dtype=np.uint64)
+        nb = np.ascontiguousarray(graph.neighbors, dtype=np.uint64)
+        n = int(graph.num_nodes)
+        lv = np.ascontiguousarray(graph.levels, dtype=np.uint64)
+        dg = np.ascontiguousarray(graph.degree_counts, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(_ffi.lib().isl_index_from_csr(
+            C.byref(cfg), n, _ptr(off), _ptr(nb) if nb.size else None,
+            _ptr(lv) if lv.size == n and n else None, _ptr(dg) if dg.size == n and n else None,
+            0 if graph.entry_point is None else 1, graph.entry_point or 0, graph.max_level,
+            0 if dimension is None else 1, dimension or 0, C.byref(h)))
+        return cls(_handle=h)
+
+    @classmethod
+    def from_device_csr(cls, d_offsets_ptr: int, d_neighbors_ptr: int, num_nodes: int,
+                        entry_point: int | None, dimension: int | None,
+                        config: LeannConfig | None = None, device: int = 0) -> "LeannIndex":
+        cfg = (config or LeannConfig())._to_c()
+        h = C.c_void_p()
+        _check(_ffi.lib().isl_index_from_device_csr(
+            C.byref(cfg), device, num_nodes, C.c_void_p(d_offsets_ptr),
+            C.c_void_p(d_neighbors_ptr), 0 if entry_point is None else 1, entry_point or 0,
+            0 if dimension is None else 1, dimension or 0, C.byref(h)))
+        return cls(_handle=h)
+
+    @classmethod
+    def from_bytes(cls, data: bytes) -> "LeannIndex":
+        """leann.rs:1064-1066"""
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data) if data else (C.c_uint8 * 1)()
+        h = C.c_void_p()
+        _check(_ffi.lib().isl_index_from_bytes(buf, len(data), C.byref(h)))
+        return cls(_handle=h)
+
+    def to_bytes(self) -> bytes:
+        """leann.rs:1059-1061"""
+        p = C.c_void_p()
+        n = C.c_size_t()
+        _check(_ffi.lib().isl_index_to_bytes(self._h, C.byref(p), C.byref(n)))
+        data = C.string_at(p, n.value)
+        _ffi.lib().isl_free_bytes(p)
+        return data
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _ffi.lib().isl_index_free(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # accessors, leann.rs:518-546
+    def __len__(self) -> int:
+        return int(_ffi.lib().isl_index_len(self._h))
+
+    def len(self) -> int:
+        return len(self)
+
+    def is_empty(self) -> bool:
+        return bool(_ffi.lib().isl_index_is_empty(self._h))
+
+    def dimension(self) -> int | None:
+        d = C.c_uint64()
+        return int(d.value) if _ffi.lib().isl_index_dimension(self._h, C.byref(d)) else None
+
+    def storage_bytes(self) -> int:
+        return int(_ffi.lib().isl_index_storage_bytes(self._h))
+
+    def is_recompute(self) -> bool:
+        return bool(_ffi.lib().isl_index_is_recompute(self._h))
+
+    def is_compact(self) -> bool:
+        return bool(_ffi.lib().isl_index_is_compact(self._h))
+
+    @property
+    def config(self) -> LeannConfig:
+        c = LeannConfigC()
+        _check(_ffi.lib().isl_index_config(self._h, C.byref(c)))
+        return LeannConfig._from_c(c)
+
+    @property
+    def entry_point(self) -> int | None:
+        e = C.c_uint64()
+        return int(e.value) if _ffi.lib().isl_index_entry_point(self._h, C.byref(e)) else None
+
+    def get_neighbors(self, node: int):
+        ptr = C.POINTER(C.c_uint64)()
+        n = C.c_size_t()
+        if not _ffi.lib().isl_index_get_neighbors(self._h, node, C.byref(ptr), C.byref(n)):
+            return None
+        return np.array([ptr[i] for i in range(n.value)], dtype=np.uint64)
+
+    # device residency
+    def upload(self, device: int = 0) -> "LeannIndex":
+        _check(_ffi.lib().isl_index_upload(self._h, device))
+        return self
+
+    def set_embeddings(self, rows, device_ptr: int | None = None, n: int | None = None,
+                       d: int | None = None) -> "LeannIndex":
+        """Attach the in-memory provider (leann.rs:111-120).  Either a host matrix, or
+        (device_ptr, n, d) for rows already resident on the index's device."""
+        if device_ptr is not None:
+            _check(_ffi.lib().isl_set_embeddings(self._h, C.c_void_p(device_ptr), n, d, 0,
+                                                 MEM_DEVICE))
+        else:
+            r = _f32(rows)
+            if r.ndim != 2 or r.shape[0] == 0:
+                raise CoreError(2, "Empty vector collection")
+            _check(_ffi.lib().isl_set_embeddings(self._h, _ptr(r), r.shape[0], r.shape[1], 0,
+                                                 MEM_HOST))
+        return self
+
+    def _attach(self, provider):
+        if isinstance(provider, InMemoryEmbeddingProvider):
+            key = id(provider.embeddings)
+            if self._provider_key != key:
+                self.set_embeddings(provider.embeddings)
+                self._provider_key = key
+        elif provider is not None:
+            raise TypeError("provider must be an InMemoryEmbeddingProvider")
+
+    # search, leann.rs:858-896
+    def search(self, query, k: int, provider=None):
+        return self.search_with_params(query, k, self.config.ef_search, provider)
+
+    def search_with_params(self, query, k: int, ef: int, provider=None):
+        ids, dist, cnt = self.search_batch(_f32(query).reshape(1, -1), k, ef, provider)
+        return [(int(ids[0, i]), float(dist[0, i])) for i in range(int(cnt[0]))]
+
+    def search_batch(self, queries, k: int, ef: int, provider=None):
+        """Batch of independent queries (Searcher::search_batch semantics, search.rs:179-181).
+        Returns (ids [nq,k] u64, dist [nq,k] f32, count [nq] u32)."""
+        self._attach(provider)
+        q = _f32(queries)
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        nq, d = q.shape
+        ids = np.zeros((nq, max(k, 1)), dtype=np.uint64)
+        dist = np.zeros((nq, max(k, 1)), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        _check(_ffi.lib().isl_search_batch(self._h, _ptr(q), nq, d, k, ef, _ptr(ids), _ptr(dist),
+                                           _ptr(cnt)))
+        return ids[:, :k], dist[:, :k], cnt
+
+    def search_batch_device(self, d_queries_ptr: int, nq: int, d: int, k: int, ef: int,
+                            d_ids_ptr: int, d_dist_ptr: int, d_count_ptr: int, stream: int = 0):
+        _check(_ffi.lib().isl_search_batch_device(
+            self._h, C.c_void_p(d_queries_ptr), nq, d, k, ef, C.c_void_p(d_ids_ptr),
+            C.c_void_p(d_dist_ptr), C.c_void_p(d_count_ptr), C.c_void_p(stream)))
+
+    def last_stats(self) -> dict:
+        s = SearchStatsC()
+        _check(_ffi.lib().isl_search_last_stats(self._h, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in SearchStatsC._fields_}
+
+
+# ----------------------------------------------------------------- search.rs
+def merge_topk(ids, scores, counts, top_k: int, id_base=None, device: int = 0):
+    """MultiIndexSearcher::search merge, search.rs:211-237.
+    ids/scores: [nlists, nq, k]; counts: [nlists, nq].  Returns (ids, scores, src, count)."""
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    scores = _f32(scores)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    nl, nq, k = ids.shape
+    base = None if id_base is None else np.ascontiguousarray(id_base, dtype=np.uint64)
+    oi = np.zeros((nq, max(top_k, 1)), dtype=np.uint64)
+    osc = np.zeros((nq, max(top_k, 1)), dtype=np.float32)
+    osrc = np.zeros((nq, max(top_k, 1)), dtype=np.uint32)
+    oc = np.zeros(nq, dtype=np.uint32)
+    _check(_ffi.lib().isl_merge_topk(nl, nq, k, _ptr(ids), _ptr(scores), _ptr(counts),
+                                     None if base is None else _ptr(base), top_k, _ptr(oi),
+                                     _ptr(osc), _ptr(osrc), _ptr(oc), MEM_HOST, device, None))
+    return oi[:, :top_k], osc[:, :top_k], osrc[:, :top_k], oc
+
+
+# --------------------------------------------------------------------- pq.rs
+class ProductQuantizer:
+    """ProductQuantizer with trained codebooks (pq.rs:116-348); training (k-means) is out of
+    scope of the search path."""
+
+    def __init__(self, dimension: int, codebooks, metric=DistanceMetric.Euclidean, device: int = 0):
+        cb = _f32(codebooks)
+        m, K, dsub = cb.shape
+        if m * dsub != dimension:
+            raise CoreError(3, f"Invalid configuration: dimension {dimension} must be divisible by "
+                               f"num_subquantizers {m}")
+        self.dimension, self.m, self.K, self.dsub = dimension, m, K, dsub
+        self._h = C.c_void_p()
+        _check(_ffi.lib().isl_pq_new(dimension, m, K, _ptr(cb), int(metric), device,
+                                     C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _ffi.lib().isl_pq_free(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def num_subquantizers(self) -> int:
+        return self.m
+
+    def bytes_per_vector(self) -> int:  # pq.rs:58-64
+        return self.m if self.K <= 256 else self.m * 2
+
+    def compression_ratio(self) -> float:  # pq.rs:168-172
+        return float(np.float32(self.dimension * 4) / np.float32(self.bytes_per_vector()))
+
+    def build_distance_tables(self, queries) -> np.ndarray:
+        q = _f32(queries)
+        single = q.ndim == 1
+        if single:
+            q = q.reshape(1, -1)
+        nq, d = q.shape
+        t = np.zeros((nq, self.m, self.K), dtype=np.float32)
+        _check(_ffi.lib().isl_pq_build_distance_tables(self._h, _ptr(q), nq, d, _ptr(t), MEM_HOST,
+                                                       None))
+        return t[0] if single else t
+
+    def table_distance(self, tables, codes) -> np.ndarray:
+        t = _f32(tables)
+        c = np.ascontiguousarray(codes, dtype=np.uint16).reshape(-1, self.m)
+        out = np.zeros(c.shape[0], dtype=np.float32)
+        _check(_ffi.lib().isl_pq_table_distance(self._h, _ptr(t), _ptr(c), c.shape[0], _ptr(out),
+                                                MEM_HOST, None))
+        return out
+
+    def asymmetric_distance(self, query, codes) -> np.ndarray:
+        q = _f32(query).ravel()
+        c = np.ascontiguousarray(codes, dtype=np.uint16).reshape(-1, self.m)
+        out = np.zeros(c.shape[0], dtype=np.float32)
+        _check(_ffi.lib().isl_pq_asymmetric_distance(self._h, _ptr(q), q.size, _ptr(c),
+                                                     c.shape[0], _ptr(out), MEM_HOST, None))
+        return out
+
+    def encode(self, vectors) -> np.ndarray:
+        v = _f32(vectors)
+        single = v.ndim == 1
+        if single:
+            v = v.reshape(1, -1)
+        n, d = v.shape
+        codes = np.zeros((n, self.m), dtype=np.uint16)
+        _check(_ffi.lib().isl_pq_encode(self._h, _ptr(v), n, d, _ptr(codes), MEM_HOST, None))
+        return codes[0] if single else codes

@@ -1,0 +1,109 @@
+"""ctypes loader for libislands_amd.so (the C ABI of include/islands_amd.h).
+
+The library is the product; this module only binds it.  There is no Python or
+CPU fallback: a missing library raises ImportError, a missing GPU surfaces as
+CoreError(Device) from the first compute call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libislands_amd.so")
+
+u64, u32, i32, f32 = C.c_uint64, C.c_uint32, C.c_int32, C.c_float
+P = C.POINTER
+
+
+class LeannConfigC(C.Structure):
+    """isl_leann_config == LeannConfig, src/core/leann.rs:322-371."""
+    _fields_ = [
+        ("m", u64), ("m0", u64), ("ef_construction", u64), ("ml", C.c_double),
+        ("max_layers", u64), ("metric", u32), ("ef_search", u64), ("beam_width", u64),
+        ("prune_ratio", f32), ("pruning_strategy", u32), ("high_degree_pruning", C.c_uint8),
+        ("hub_percentile", f32), ("is_compact", C.c_uint8), ("is_recompute", C.c_uint8),
+    ]
+
+
+class SearchStatsC(C.Structure):
+    _fields_ = [("queries", u64), ("expansions", u64), ("edges", u64), ("evals", u64),
+                ("pushes", u64), ("exact_path", u64), ("kernel_ms", C.c_double)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/islands_amd.h
+SIGNATURES = {
+    "isl_last_error_message": (C.c_char_p, []),
+    "isl_last_error_expected": (u64, []),
+    "isl_last_error_actual": (u64, []),
+    "isl_last_error_node": (u64, []),
+    "isl_status_name": (C.c_char_p, [i32]),
+    "isl_abi_version": (u32, []),
+    "isl_device_count": (i32, []),
+    "isl_leann_config_paper_default": (None, [P(LeannConfigC)]),
+    "isl_leann_config_fast": (None, [P(LeannConfigC)]),
+    "isl_leann_config_accurate": (None, [P(LeannConfigC)]),
+    "isl_leann_config_validate": (i32, [P(LeannConfigC)]),
+    "isl_index_new": (i32, [P(LeannConfigC), P(C.c_void_p)]),
+    "isl_index_from_csr": (i32, [P(LeannConfigC), u64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, i32, u64, u64, i32, u64, P(C.c_void_p)]),
+    "isl_index_from_device_csr": (i32, [P(LeannConfigC), i32, u64, C.c_void_p, C.c_void_p, i32,
+                                        u64, i32, u64, P(C.c_void_p)]),
+    "isl_index_from_bytes": (i32, [C.c_void_p, C.c_size_t, P(C.c_void_p)]),
+    "isl_index_to_bytes": (i32, [C.c_void_p, P(C.c_void_p), P(C.c_size_t)]),
+    "isl_free_bytes": (None, [C.c_void_p]),
+    "isl_index_free": (None, [C.c_void_p]),
+    "isl_index_len": (u64, [C.c_void_p]),
+    "isl_index_is_empty": (i32, [C.c_void_p]),
+    "isl_index_dimension": (i32, [C.c_void_p, P(u64)]),
+    "isl_index_storage_bytes": (u64, [C.c_void_p]),
+    "isl_index_is_recompute": (i32, [C.c_void_p]),
+    "isl_index_is_compact": (i32, [C.c_void_p]),
+    "isl_index_config": (i32, [C.c_void_p, P(LeannConfigC)]),
+    "isl_index_entry_point": (i32, [C.c_void_p, P(u64)]),
+    "isl_index_max_level": (u64, [C.c_void_p]),
+    "isl_index_get_neighbors": (i32, [C.c_void_p, u64, P(P(u64)), P(C.c_size_t)]),
+    "isl_index_upload": (i32, [C.c_void_p, i32]),
+    "isl_set_embeddings": (i32, [C.c_void_p, C.c_void_p, u64, u64, i32, i32]),
+    "isl_search_batch": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64, C.c_void_p,
+                               C.c_void_p, C.c_void_p]),
+    "isl_search_batch_device": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "isl_search": (i32, [C.c_void_p, C.c_void_p, u64, u64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "isl_search_last_stats": (i32, [C.c_void_p, P(SearchStatsC)]),
+    "isl_distance": (i32, [i32, C.c_void_p, u64, C.c_void_p, u64, P(f32)]),
+    "isl_distance_squared": (i32, [i32, C.c_void_p, u64, C.c_void_p, u64, P(f32)]),
+    "isl_distance_batch": (i32, [i32, C.c_void_p, u64, C.c_void_p, u64, u64, C.c_void_p, i32, i32,
+                                 C.c_void_p]),
+    "isl_normalize_rows": (i32, [C.c_void_p, u64, u64, i32, i32, C.c_void_p]),
+    "isl_merge_topk": (i32, [u64, u64, u64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u64,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, i32, i32,
+                             C.c_void_p]),
+    "isl_pq_new": (i32, [u64, u64, u64, C.c_void_p, i32, i32, P(C.c_void_p)]),
+    "isl_pq_free": (None, [C.c_void_p]),
+    "isl_pq_build_distance_tables": (i32, [C.c_void_p, C.c_void_p, u64, u64, C.c_void_p, i32,
+                                           C.c_void_p]),
+    "isl_pq_table_distance": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, u64, C.c_void_p, i32,
+                                    C.c_void_p]),
+    "isl_pq_asymmetric_distance": (i32, [C.c_void_p, C.c_void_p, u64, C.c_void_p, u64,
+                                         C.c_void_p, i32, C.c_void_p]),
+    "isl_pq_encode": (i32, [C.c_void_p, C.c_void_p, u64, u64, C.c_void_p, i32, C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C islands_amd/csrc` (there is no CPU fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib

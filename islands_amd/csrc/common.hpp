@@ -1,0 +1,113 @@
+// Internal declarations shared by the translation units of libislands_amd.so.
+// Nothing here is part of the ABI (see include/islands_amd.h for that).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/islands_amd.h"
+
+namespace isl {
+
+// ---- thread-local error record (CoreError payloads, src/core/error.rs:9-62) ----
+struct ErrorRecord {
+  std::string message;
+  uint64_t expected = 0, actual = 0, node = 0;
+};
+ErrorRecord& last_error();
+isl_status fail(isl_status st, const char* fmt, ...);
+isl_status fail_dim(uint64_t expected, uint64_t actual);
+isl_status fail_node(uint64_t node);
+
+#define ISL_HIP(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess)                                                               \
+      return ::isl::fail(ISL_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr,                \
+                         hipGetErrorString(_e), __FILE__, __LINE__);                    \
+  } while (0)
+
+#define ISL_TRY(expr)            \
+  do {                           \
+    isl_status _s = (expr);      \
+    if (_s != ISL_OK) return _s; \
+  } while (0)
+
+// Selects `device` after checking that it exists and is a gfx950 part.
+isl_status use_device(int32_t device);
+
+// ---- per-index device workspace for the search kernels ----
+struct SearchWorkspace {
+  uint32_t slots = 0;          // resident waves the scratch is sized for
+  uint32_t ovf_bits = 0;       // log2 entries of the per-slot overflow visited table
+  uint32_t* ovf_tab = nullptr; // [slots][1 << ovf_bits], EMPTY-filled between queries
+  uint32_t cap_q = 0;          // per-query arrays sized for this many queries
+  uint32_t* status = nullptr;  // [cap_q]
+  uint64_t* payload = nullptr; // [cap_q]
+  uint32_t* ctr = nullptr;     // [cap_q][4]  H,E,V,pushes
+  uint32_t* ticket = nullptr;  // work-queue heads (fast, exact)
+  uint32_t* redo = nullptr;    // [cap_q] query ids routed to the exact kernel
+  // exact-kernel scratch
+  uint32_t exact_slots = 0;
+  uint64_t cand_cap = 0;       // entries per slot in the candidate heap
+  float* cand_d = nullptr;     // [exact_slots][cand_cap]
+  uint32_t* cand_id = nullptr;
+  uint32_t* vis_bits = nullptr; // [exact_slots][ceil(max_id/32)] visited bitmap
+  uint64_t vis_words = 0;
+  uint32_t* ulist = nullptr;   // [exact_slots][max_degree] unvisited ids of one hop
+  uint32_t ulist_cap = 0;
+  // staging for the host-pointer entry point
+  float* q_stage = nullptr;
+  uint64_t q_stage_bytes = 0;
+  uint64_t* ids_stage = nullptr;
+  float* dist_stage = nullptr;
+  uint32_t* count_stage = nullptr;
+  uint64_t out_stage_slots = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+}  // namespace isl
+
+// The opaque handle of the ABI.  Host side mirrors LeannIndex (leann.rs:492-500).
+struct isl_index {
+  isl_leann_config cfg{};
+  // CsrGraph, leann.rs:193-208 (host copy; may be absent for device-born graphs)
+  bool host_csr_valid = true;
+  std::vector<uint64_t> node_offsets{0};
+  std::vector<uint64_t> neighbors;
+  std::vector<uint64_t> levels;
+  std::vector<uint64_t> degree_counts;
+  bool has_entry = false;
+  uint64_t entry_point = 0;
+  uint64_t max_level = 0;
+  uint64_t num_nodes = 0;
+  bool has_dimension = false;
+  uint64_t dimension = 0;
+
+  // device residency
+  int32_t device = -1;
+  uint64_t* d_off = nullptr;  // [num_nodes + 1]
+  uint32_t* d_adj = nullptr;  // [nnz] (duplicates within a row removed, first occurrence kept)
+  uint64_t nnz = 0;
+  uint32_t max_degree = 0;
+  // in-memory provider (leann.rs:104-159): nvec rows, `stride` floats apart
+  float* d_emb = nullptr;
+  uint64_t nvec = 0, emb_d = 0, emb_stride = 0;
+
+  mutable std::mutex mu;  // serialises searches that share the workspace
+  mutable isl::SearchWorkspace ws;
+  mutable isl_search_stats stats{};
+};
+
+namespace isl {
+isl_status materialise_host_csr(const isl_index* idx);
+void free_workspace(SearchWorkspace& ws);
+}  // namespace isl

@@ -1,0 +1,974 @@
+// LEANN best-first search on gfx950: one 64-lane wavefront per query.
+//
+// Replaces LeannIndex::search_with_params / search_layer_recompute
+// (src/core/leann.rs:868-988) with the in-memory provider (leann.rs:104-159)
+// and DistanceMetric::calculate (src/core/distance.rs:37-122).
+//
+// Parity design:
+//   * distances are computed in the reference's exact operation order -- one
+//     lane owns one candidate row and runs the strictly sequential f32 chain
+//     (separate multiply and add roundings, -ffp-contract=off), so every
+//     distance is bit-identical to the Rust scalar loop and every traversal
+//     decision (strict float compares at leann.rs:925,959) matches.
+//     Rows reach the lanes through an LDS tile that is filled with fully
+//     coalesced 16-byte loads (4 rows x 256 B per wave-instruction) and read
+//     back row-per-lane with conflict-free ds_read_b128 (row pitch 68 floats).
+//   * fast kernel: the result set R (<= ef entries, key = (OrderedFloat d, id))
+//     lives in registers as a sorted array spread over the wave; the candidate
+//     heap is implicit (live candidates are exactly the unexpanded entries of
+//     R).  Situations where the reference's BinaryHeap internals become
+//     observable (distance ties inside the returned prefix, or a tie between
+//     an evicted entry and the new worst) are detected and the query is re-run
+//     by the exact kernel.
+//   * exact kernel: emulates Rust's BinaryHeap push/pop/into_iter byte for byte
+//     (candidates in HBM scratch, results in LDS) for those queries, for
+//     ef > 512 and for adjacency rows longer than 64.
+#include "device_common.cuh"
+
+#include <algorithm>
+
+namespace {
+
+using namespace isl_dev;
+
+constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t FLAG_EXP = 0x80000000u;
+constexpr uint32_t ID_MASK = 0x7FFFFFFFu;
+
+// per-query status words written by the kernels
+enum : uint32_t {
+  QS_OK = 0,
+  QS_NODE_NOT_FOUND = 5,
+  QS_REDO = 0x100,     // fast kernel gave up -> exact kernel
+  QS_SCRATCH = 0x101   // exact kernel ran out of candidate scratch
+};
+
+struct SearchParams {
+  const uint64_t* off;
+  const uint32_t* adj;
+  uint64_t num_nodes;
+  const float* emb;
+  uint64_t nvec;
+  uint64_t stride;  // floats between rows
+  uint32_t d;
+  const float* queries;
+  uint32_t nq;
+  uint32_t k, ef;
+  float prune_ratio;
+  uint32_t prune_strategy;
+  uint32_t entry;
+  uint64_t* out_ids;
+  float* out_dist;
+  uint32_t* out_count;
+  uint32_t* status;
+  uint64_t* payload;
+  uint32_t* ctr;     // [nq][4]
+  uint32_t* ticket;  // [0] fast queue head, [1] redo count, [2] exact queue head
+  uint32_t* redo;    // [nq]
+  uint32_t hbits;    // LDS visited table: 1 << hbits entries
+  uint32_t* otab;    // overflow visited table in HBM, per slot
+  uint32_t obits;
+  // exact-kernel scratch
+  float* cand_d;
+  uint32_t* cand_id;
+  uint64_t cand_cap;
+  uint32_t* vis_bits;
+  uint64_t vis_words;
+  uint32_t* ulist;
+  uint32_t ulist_cap;
+};
+
+// ------------------------------------------------------------- sorted result set
+// R as a sorted array (ascending (OrderedFloat d, id)) of up to 64*S entries; entry e
+// lives in slot e / 64 of lane e % 64.  id bit 31 marks "already expanded".
+template <int S>
+struct RSet {
+  float d[S];
+  uint32_t id[S];
+  uint32_t len;  // wave-uniform
+
+  __device__ void init() {
+#pragma unroll
+    for (int s = 0; s < S; ++s) { d[s] = 0.0f; id[s] = 0u; }
+    len = 0;
+  }
+  __device__ float dist_at(uint32_t e) const {
+    float r = 0.0f;
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      if ((int)(e >> 6) == s) r = rl_f(d[s], e & 63);
+    return r;
+  }
+  __device__ uint32_t id_at(uint32_t e) const {
+    uint32_t r = 0;
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      if ((int)(e >> 6) == s) r = rl_u(id[s], e & 63);
+    return r;
+  }
+  // first entry not yet expanded, or 0xFFFFFFFF
+  __device__ uint32_t first_unexpanded() const {
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      uint32_t e = s * 64 + lane;
+      uint64_t m = ballot(e < len && !(id[s] & FLAG_EXP));
+      if (m) return s * 64 + (uint32_t)__ffsll((long long)m) - 1;
+    }
+    return 0xFFFFFFFFu;
+  }
+  __device__ void mark_expanded(uint32_t e) {
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      if ((int)(e >> 6) == s && lane == (int)(e & 63)) id[s] |= FLAG_EXP;
+  }
+  // Inserts (nd, nid) keeping the order; the entry pushed past index cap-1 is lost.
+  __device__ void insert(float nd, uint32_t nid) {
+    const int lane = threadIdx.x;
+    const uint32_t nk = ordkey(nd);
+    uint32_t pos = 0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      uint32_t e = s * 64 + lane;
+      uint32_t ek = ordkey(d[s]);
+      bool less = e < len && (ek < nk || (ek == nk && (id[s] & ID_MASK) < nid));
+      pos += (uint32_t)__popcll(ballot(less));
+    }
+#pragma unroll
+    for (int s = S - 1; s >= 0; --s) {
+      float ud = __shfl_up(d[s], 1);
+      uint32_t ui = __shfl_up(id[s], 1);
+      if (s > 0) {
+        float pd = rl_f(d[s - 1], 63);
+        uint32_t pi = rl_u(id[s - 1], 63);
+        if (lane == 0) { ud = pd; ui = pi; }
+      }
+      uint32_t e = s * 64 + lane;
+      if (e > pos) { d[s] = ud; id[s] = ui; }
+      else if (e == pos) { d[s] = nd; id[s] = nid; }
+    }
+    len += 1;
+  }
+};
+
+// ------------------------------------------------------------------ fast kernel
+template <int S, int METRIC>
+__global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const uint32_t hcap = 1u << p.hbits;
+  const uint32_t hmask = hcap - 1;
+  const uint32_t hlimit = hcap - hcap / 4;  // load factor 0.75
+  uint32_t* htab = reinterpret_cast<uint32_t*>(smem);
+  float* tile = reinterpret_cast<float*>(smem + (size_t)hcap * 4);
+  uint32_t* scratch = reinterpret_cast<uint32_t*>(tile + TILE_ROWS * TILE_LD);
+  float* qs = reinterpret_cast<float*>(scratch + 64);
+  const uint32_t ocap = 1u << p.obits;
+  const uint32_t omask = ocap - 1;
+  const uint32_t olimit = ocap - ocap / 4;
+  uint32_t* otab = p.otab + (size_t)blockIdx.x * ocap;
+  const uint32_t ef = p.ef;
+
+  for (;;) {
+    uint32_t qi = 0;
+    if (lane == 0) qi = atomicAdd(&p.ticket[0], 1u);
+    qi = uni(qi);
+    if (qi >= p.nq) break;
+
+    for (uint32_t i = lane; i < hcap; i += 64) htab[i] = EMPTY;
+    const float q_norm = load_query<METRIC>(p.queries, qi, p.d, qs);  // syncs
+
+    RSet<S> rs;
+    rs.init();
+    uint32_t hcount = 0, ocount = 0;
+    bool ovf = false;
+    uint32_t status = QS_OK;
+    uint64_t payload = 0;
+    uint32_t cH = 0, cE = 0, cV = 0, cP = 0;
+
+    // entry point: provider.compute_embedding(entry) + distance, leann.rs:911-916
+    if ((uint64_t)p.entry >= p.nvec) {
+      status = QS_NODE_NOT_FOUND;
+      payload = p.entry;
+    } else {
+      float ed = wave_distances<METRIC>(p.emb, p.stride, p.d, p.entry, 1, qs, tile, q_norm);
+      ed = rl_f(ed, 0);
+      cV = 1;
+      if (lane == 0) htab[hslot(p.entry, p.hbits)] = p.entry;
+      hcount = 1;
+      rs.insert(ed, p.entry);
+      cP = 1;
+      __syncthreads();
+    }
+
+    while (status == QS_OK) {
+      // candidates.pop(): the smallest unexpanded key of R (leann.rs:922); when none is
+      // left every remaining candidate is farther than the worst result -> break (:924-928)
+      uint32_t e = rs.first_unexpanded();
+      if (e == 0xFFFFFFFFu) break;
+      uint32_t cid = rs.id_at(e) & ID_MASK;
+      rs.mark_expanded(e);
+      if ((uint64_t)cid >= p.num_nodes) continue;  // get_neighbors -> None, leann.rs:227-229
+      uint64_t o0 = p.off[cid], o1 = p.off[cid + 1];
+      uint32_t deg = (uint32_t)(o1 - o0);
+      cH += 1;
+      cE += deg;
+      if (deg == 0) continue;
+      if (deg > 64) { status = QS_REDO; break; }  // long rows: exact kernel
+      bool active = (uint32_t)lane < deg;
+      uint32_t nid = active ? p.adj[o0 + lane] : EMPTY;
+
+      // visited.insert(n), leann.rs:933-937 (rows hold no duplicate ids on the device)
+      if (!ovf && hcount + deg > hlimit) ovf = true;
+      bool is_new = false;
+      if (active) {
+        uint32_t h = hslot(nid, p.hbits);
+        if (!ovf) {
+          for (;;) {
+            uint32_t old = atomicCAS(&htab[h], EMPTY, nid);
+            if (old == EMPTY) { is_new = true; break; }
+            if (old == nid) break;
+            h = (h + 1) & hmask;
+          }
+        } else {
+          bool found = false;
+          for (;;) {
+            uint32_t cur = htab[h];
+            if (cur == nid) { found = true; break; }
+            if (cur == EMPTY) break;
+            h = (h + 1) & hmask;
+          }
+          if (!found) {
+            uint32_t g = hslot(nid, p.obits);
+            for (;;) {
+              uint32_t old = atomicCAS(&otab[g], EMPTY, nid);
+              if (old == EMPTY) { is_new = true; break; }
+              if (old == nid) break;
+              g = (g + 1) & omask;
+            }
+          }
+        }
+      }
+      uint64_t nm = ballot(is_new);
+      uint32_t nu = (uint32_t)__popcll(nm);
+      if (!ovf) hcount += nu;
+      else {
+        ocount += nu;
+        if (ocount > olimit) { status = QS_REDO; break; }
+      }
+      if (nu == 0) continue;  // leann.rs:939-941
+
+      // compact the unvisited ids, CSR order preserved
+      uint32_t rank = (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
+      if (is_new) scratch[rank] = nid;
+      __syncthreads();
+      uint32_t uid = (uint32_t)lane < nu ? scratch[lane] : 0u;
+      __syncthreads();
+
+      uint32_t keep = prune_keep(p.prune_ratio, p.prune_strategy, nu, rs.len, ef);  // :944
+      // compute_embeddings_batch, leann.rs:947: the first missing id fails the query
+      uint64_t bad = ballot((uint32_t)lane < keep && (uint64_t)uid >= p.nvec);
+      if (bad) {
+        int bl = __ffsll((long long)bad) - 1;
+        status = QS_NODE_NOT_FOUND;
+        payload = rl_u(uid, bl);
+        break;
+      }
+      cV += keep;
+      float nd = wave_distances<METRIC>(p.emb, p.stride, p.d, uid, keep, qs, tile, q_norm);
+
+      // leann.rs:953-970 in CSR order; worst = results.peek()
+      uint64_t pending = keep >= 64 ? ~0ull : ((1ull << keep) - 1ull);
+      while (pending) {
+        bool full = rs.len >= ef;
+        float worst = rs.len ? rs.dist_at(rs.len - 1) : 0.0f;
+        bool pass = !full || rs.len == 0 || nd < worst;  // raw f32 `<`, leann.rs:959
+        uint64_t pm = ballot(pass) & pending;
+        if (!pm) break;
+        int r = __ffsll((long long)pm) - 1;
+        float id_d = rl_f(nd, r);
+        uint32_t id_i = rl_u(uid, r);
+        if (full) {
+          // results.push + pop: the old worst leaves.  It stays in the reference's candidate
+          // heap; that only matters if it ties with the new worst.
+          float old_worst = worst;
+          rs.insert(id_d, id_i);
+          rs.len = ef;
+          float new_worst = rs.dist_at(ef - 1);
+          if (ordkey(old_worst) == ordkey(new_worst)) status = QS_REDO;
+        } else {
+          rs.insert(id_d, id_i);
+        }
+        cP += 1;
+        pending &= ~((2ull << r) - 1ull);
+        if (r == 63) pending = 0;
+      }
+    }
+
+    // results sorted by distance, take(k): leann.rs:984-986, :895
+    uint32_t outn = rs.len < p.k ? rs.len : p.k;
+    if (status == QS_OK) {
+      // equal distances inside the returned prefix (or across its boundary) are ordered by
+      // BinaryHeap array order in the reference: let the exact kernel reproduce that
+      uint32_t chk = rs.len < p.k + 1 ? rs.len : p.k + 1;
+      bool tie = false;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        uint32_t e = s * 64 + lane;
+        float nxt = __shfl_down(rs.d[s], 1);
+        if (s + 1 < S) {
+          float nd0 = rl_f(rs.d[s + 1 < S ? s + 1 : s], 0);
+          if (lane == 63) nxt = nd0;
+        }
+        if (e + 1 < chk && ordkey(rs.d[s]) == ordkey(nxt)) tie = true;
+      }
+      if (ballot(tie)) status = QS_REDO;
+    }
+    if (status == QS_OK) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        uint32_t e = s * 64 + lane;
+        if (e < outn) {
+          p.out_ids[(uint64_t)qi * p.k + e] = (uint64_t)(rs.id[s] & ID_MASK);
+          p.out_dist[(uint64_t)qi * p.k + e] = rs.d[s];
+        }
+      }
+    }
+    if (lane == 0) {
+      p.status[qi] = status;
+      p.payload[qi] = payload;
+      p.out_count[qi] = status == QS_OK ? outn : 0u;
+      p.ctr[qi * 4 + 0] = cH;
+      p.ctr[qi * 4 + 1] = cE;
+      p.ctr[qi * 4 + 2] = cV;
+      p.ctr[qi * 4 + 3] = cP;
+      if (status == QS_REDO) p.redo[atomicAdd(&p.ticket[1], 1u)] = qi;
+    }
+    if (ovf) {  // leave the overflow table empty for the next query of this slot
+      for (uint32_t i = lane; i < ocap; i += 64) otab[i] = EMPTY;
+    }
+    __syncthreads();
+  }
+}
+
+// ----------------------------------------------------------------- exact kernel
+// Rust BinaryHeap ([external]: std): max-heap w.r.t. `less_eq`.  Operated by lane 0 only.
+struct ResultOrder {  // (OrderedFloat<f32>, u64), leann.rs:908
+  __device__ static bool le(float ad, uint32_t ai, float bd, uint32_t bi) {
+    uint32_t ka = ordkey(ad), kb = ordkey(bd);
+    return ka < kb || (ka == kb && ai <= bi);
+  }
+};
+struct CandOrder {  // Reverse<(OrderedFloat<f32>, u64)>, leann.rs:907
+  __device__ static bool le(float ad, uint32_t ai, float bd, uint32_t bi) {
+    return ResultOrder::le(bd, bi, ad, ai);
+  }
+};
+
+template <class ORD>
+__device__ void heap_sift_up(float* hd, uint32_t* hi, uint64_t start, uint64_t pos) {
+  float ed = hd[pos];
+  uint32_t ei = hi[pos];
+  while (pos > start) {
+    uint64_t parent = (pos - 1) / 2;
+    if (ORD::le(ed, ei, hd[parent], hi[parent])) break;
+    hd[pos] = hd[parent];
+    hi[pos] = hi[parent];
+    pos = parent;
+  }
+  hd[pos] = ed;
+  hi[pos] = ei;
+}
+
+template <class ORD>
+__device__ void heap_push(float* hd, uint32_t* hi, uint64_t& len, float d, uint32_t id) {
+  hd[len] = d;
+  hi[len] = id;
+  len += 1;
+  heap_sift_up<ORD>(hd, hi, 0, len - 1);
+}
+
+template <class ORD>
+__device__ void heap_pop(float* hd, uint32_t* hi, uint64_t& len, float& od, uint32_t& oi) {
+  // Vec::pop the last item; if the heap is not empty swap it with the root and
+  // sift_down_to_bottom(0) + sift_up
+  len -= 1;
+  float itd = hd[len];
+  uint32_t iti = hi[len];
+  if (len > 0) {
+    float rd = hd[0];
+    uint32_t ri = hi[0];
+    uint64_t end = len, pos = 0, child = 1;
+    while (end >= 2 && child <= end - 2) {
+      if (ORD::le(hd[child], hi[child], hd[child + 1], hi[child + 1])) child += 1;
+      hd[pos] = hd[child];
+      hi[pos] = hi[child];
+      pos = child;
+      child = 2 * pos + 1;
+    }
+    if (child == end - 1) {
+      hd[pos] = hd[child];
+      hi[pos] = hi[child];
+      pos = child;
+    }
+    hd[pos] = itd;
+    hi[pos] = iti;
+    heap_sift_up<ORD>(hd, hi, 0, pos);
+    itd = rd;
+    iti = ri;
+  }
+  od = itd;
+  oi = iti;
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const uint32_t ef = p.ef;
+  float* tile = reinterpret_cast<float*>(smem);
+  uint32_t* scratch = reinterpret_cast<uint32_t*>(tile + TILE_ROWS * TILE_LD);  // 64 ids
+  float* dscratch = reinterpret_cast<float*>(scratch + 64);                     // 64 distances
+  uint32_t* ctl = reinterpret_cast<uint32_t*>(dscratch + 64);                   // 8 control words
+  float* res_d = reinterpret_cast<float*>(ctl + 8);                             // ef + 1
+  uint32_t* res_i = reinterpret_cast<uint32_t*>(res_d + (ef + 1));
+  float* qs = reinterpret_cast<float*>(res_i + (ef + 1));
+  qs = reinterpret_cast<float*>(((uintptr_t)qs + 15) & ~(uintptr_t)15);
+
+  float* cand_d = p.cand_d + (size_t)blockIdx.x * p.cand_cap;
+  uint32_t* cand_i = p.cand_id + (size_t)blockIdx.x * p.cand_cap;
+  uint32_t* vis = p.vis_bits + (size_t)blockIdx.x * p.vis_words;
+  uint32_t* ulist = p.ulist + (size_t)blockIdx.x * p.ulist_cap;
+
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&p.ticket[2], 1u);
+    t = uni(t);
+    uint32_t nredo = *((volatile uint32_t*)&p.ticket[1]);
+    if (t >= nredo) break;
+    const uint32_t qi = p.redo[t];
+
+    for (uint64_t i = lane; i < p.vis_words; i += 64) vis[i] = 0u;
+    const float q_norm = load_query<METRIC>(p.queries, qi, p.d, qs);
+    __threadfence_block();
+
+    uint64_t clen = 0, rlen = 0;  // lane 0 only
+    uint32_t status = QS_OK;
+    uint64_t payload = 0;
+    uint32_t cH = 0, cE = 0, cV = 0, cP = 0;
+
+    if ((uint64_t)p.entry >= p.nvec) {
+      status = QS_NODE_NOT_FOUND;
+      payload = p.entry;
+    } else {
+      float ed = wave_distances<METRIC>(p.emb, p.stride, p.d, p.entry, 1, qs, tile, q_norm);
+      cV = 1;
+      if (lane == 0) {
+        vis[p.entry >> 5] |= 1u << (p.entry & 31);
+        heap_push<CandOrder>(cand_d, cand_i, clen, ed, p.entry);
+        uint64_t rl = rlen;
+        heap_push<ResultOrder>(res_d, res_i, rl, ed, p.entry);
+        rlen = rl;
+      }
+      cP = 1;
+      __threadfence_block();
+      __syncthreads();
+    }
+
+    while (status == QS_OK) {
+      // lane 0: candidates.pop() + termination test, leann.rs:922-928
+      if (lane == 0) {
+        uint32_t go = 0, cid = 0;
+        if (clen > 0) {
+          float cd;
+          heap_pop<CandOrder>(cand_d, cand_i, clen, cd, cid);
+          go = 1;
+          if (rlen > 0 && rlen >= ef && ordkey(cd) > ordkey(res_d[0])) go = 0;
+        }
+        ctl[0] = go;
+        ctl[1] = cid;
+      }
+      __syncthreads();
+      uint32_t go = ctl[0], cid = ctl[1];
+      __syncthreads();
+      if (!go) break;
+      if ((uint64_t)cid >= p.num_nodes) continue;
+      uint64_t o0 = p.off[cid], o1 = p.off[cid + 1];
+      uint32_t deg = (uint32_t)(o1 - o0);
+      cH += 1;
+      cE += deg;
+      // unvisited = neighbors.filter(visited.insert), leann.rs:933-937
+      uint32_t nu = 0;
+      for (uint32_t base = 0; base < deg; base += 64) {
+        bool active = base + lane < deg;
+        uint32_t nid = active ? p.adj[o0 + base + lane] : 0u;
+        bool is_new = false;
+        if (active) {
+          if (((uint64_t)nid >> 5) < p.vis_words) {
+            uint32_t bit = 1u << (nid & 31);
+            uint32_t old = atomicOr(&vis[nid >> 5], bit);
+            is_new = !(old & bit);
+          } else {
+            is_new = true;  // beyond every valid id: reported as NodeNotFound below
+          }
+        }
+        uint64_t nm = ballot(is_new);
+        uint32_t rank = (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
+        if (is_new) ulist[nu + rank] = nid;
+        nu += (uint32_t)__popcll(nm);
+      }
+      if (nu == 0) continue;
+      __threadfence_block();
+      __syncthreads();
+      uint32_t rl_now = 0;
+      if (lane == 0) ctl[2] = (uint32_t)rlen;
+      __syncthreads();
+      rl_now = ctl[2];
+      uint32_t keep = prune_keep(p.prune_ratio, p.prune_strategy, nu, rl_now, ef);
+      // compute_embeddings_batch over all kept ids first, leann.rs:947
+      uint32_t first_bad = 0xFFFFFFFFu;
+      for (uint32_t base = 0; base < keep && first_bad == 0xFFFFFFFFu; base += 64) {
+        uint32_t uid = base + lane < keep ? ulist[base + lane] : 0u;
+        uint64_t bad = ballot(base + lane < keep && (uint64_t)uid >= p.nvec);
+        if (bad) first_bad = rl_u(uid, __ffsll((long long)bad) - 1);
+      }
+      if (first_bad != 0xFFFFFFFFu) {
+        status = QS_NODE_NOT_FOUND;
+        payload = first_bad;
+        break;
+      }
+      cV += keep;
+      for (uint32_t base = 0; base < keep && status == QS_OK; base += 64) {
+        uint32_t R = keep - base < 64 ? keep - base : 64;
+        uint32_t uid = (uint32_t)lane < R ? ulist[base + lane] : 0u;
+        float nd = wave_distances<METRIC>(p.emb, p.stride, p.d, uid, R, qs, tile, q_norm);
+        if ((uint32_t)lane < R) {
+          dscratch[lane] = nd;
+          scratch[lane] = uid;
+        }
+        __syncthreads();
+        if (lane == 0) {
+          uint32_t pushes = 0, st = QS_OK;
+          for (uint32_t r = 0; r < R; ++r) {  // leann.rs:953-970
+            float d = dscratch[r];
+            uint32_t id = scratch[r];
+            bool should_add = rlen < ef || rlen == 0 || d < res_d[0];
+            if (should_add) {
+              if (clen >= p.cand_cap) { st = QS_SCRATCH; break; }
+              heap_push<CandOrder>(cand_d, cand_i, clen, d, id);
+              heap_push<ResultOrder>(res_d, res_i, rlen, d, id);
+              pushes++;
+              if (rlen > ef) {
+                float dd;
+                uint32_t di;
+                heap_pop<ResultOrder>(res_d, res_i, rlen, dd, di);
+              }
+            }
+          }
+          ctl[3] = pushes;
+          ctl[4] = st;
+        }
+        __syncthreads();
+        cP += ctl[3];
+        status = ctl[4];
+        __syncthreads();
+      }
+    }
+
+    // results.into_iter() (array order) + stable sort by distance, leann.rs:984-986
+    if (lane == 0) {
+      for (uint64_t i = 1; i < rlen; ++i) {
+        float d = res_d[i];
+        uint32_t id = res_i[i];
+        uint64_t j = i;
+        while (j > 0 && d < res_d[j - 1]) {  // partial_cmp == Less only
+          res_d[j] = res_d[j - 1];
+          res_i[j] = res_i[j - 1];
+          j--;
+        }
+        res_d[j] = d;
+        res_i[j] = id;
+      }
+      ctl[5] = (uint32_t)rlen;
+    }
+    __syncthreads();
+    uint32_t rl = ctl[5];
+    uint32_t outn = rl < p.k ? rl : p.k;
+    if (status == QS_OK) {
+      for (uint32_t e = lane; e < outn; e += 64) {
+        p.out_ids[(uint64_t)qi * p.k + e] = (uint64_t)res_i[e];
+        p.out_dist[(uint64_t)qi * p.k + e] = res_d[e];
+      }
+    }
+    if (lane == 0) {
+      p.status[qi] = status;
+      p.payload[qi] = payload;
+      p.out_count[qi] = status == QS_OK ? outn : 0u;
+      p.ctr[qi * 4 + 0] = cH;
+      p.ctr[qi * 4 + 1] = cE;
+      p.ctr[qi * 4 + 2] = cV;
+      p.ctr[qi * 4 + 3] = cP;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ launchers
+struct FastGeom {
+  uint32_t hbits;
+  size_t lds;
+};
+
+FastGeom fast_geometry(uint32_t ef, uint32_t d) {
+  // visited capacity grows with ef (V is roughly 10-30 x ef); overflow goes to HBM
+  uint32_t hbits = ef <= 32 ? 10 : ef <= 64 ? 11 : ef <= 160 ? 12 : ef <= 320 ? 13 : 14;
+  size_t lds = ((size_t)4 << hbits) + (size_t)TILE_ROWS * TILE_LD * 4 + 64 * 4 +
+               (size_t)((d + 3) / 4 * 4) * 4;
+  return {hbits, lds};
+}
+
+size_t exact_lds(uint32_t ef, uint32_t d) {
+  return (size_t)TILE_ROWS * TILE_LD * 4 + 64 * 4 + 64 * 4 + 8 * 4 + (size_t)(ef + 1) * 8 + 16 +
+         (size_t)((d + 3) / 4 * 4) * 4;
+}
+
+template <typename K>
+void launch_one(K kernel, uint32_t grid, size_t lds, hipStream_t st, const SearchParams& p) {
+  // more than 64 KiB of dynamic LDS needs the opt-in attribute
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, st, p);
+}
+
+template <int S>
+void launch_fast(int metric, uint32_t grid, size_t lds, hipStream_t st, const SearchParams& p) {
+  switch (metric) {
+    case ISL_METRIC_COSINE: launch_one(leann_search_fast<S, ISL_METRIC_COSINE>, grid, lds, st, p); break;
+    case ISL_METRIC_EUCLIDEAN: launch_one(leann_search_fast<S, ISL_METRIC_EUCLIDEAN>, grid, lds, st, p); break;
+    case ISL_METRIC_DOT: launch_one(leann_search_fast<S, ISL_METRIC_DOT>, grid, lds, st, p); break;
+    default: launch_one(leann_search_fast<S, ISL_METRIC_MANHATTAN>, grid, lds, st, p); break;
+  }
+}
+
+void launch_exact(int metric, uint32_t grid, size_t lds, hipStream_t st, const SearchParams& p) {
+  switch (metric) {
+    case ISL_METRIC_COSINE: launch_one(leann_search_exact<ISL_METRIC_COSINE>, grid, lds, st, p); break;
+    case ISL_METRIC_EUCLIDEAN: launch_one(leann_search_exact<ISL_METRIC_EUCLIDEAN>, grid, lds, st, p); break;
+    case ISL_METRIC_DOT: launch_one(leann_search_exact<ISL_METRIC_DOT>, grid, lds, st, p); break;
+    default: launch_one(leann_search_exact<ISL_METRIC_MANHATTAN>, grid, lds, st, p); break;
+  }
+}
+
+__global__ void fill_u32_kernel(uint32_t* p, uint64_t n, uint32_t v) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+constexpr uint32_t kExactSlots = 128;
+constexpr uint32_t kOvfBits = 16;
+constexpr uint32_t kMaxExactEf = 4096;
+
+template <typename T>
+isl_status ensure(T*& ptr, uint64_t& have, uint64_t want) {
+  if (have >= want && ptr) return ISL_OK;
+  if (ptr) (void)hipFree(ptr);
+  ptr = nullptr;
+  have = 0;
+  ISL_HIP(hipMalloc(&ptr, want * sizeof(T)));
+  have = want;
+  return ISL_OK;
+}
+
+isl_status prepare_workspace(const isl_index* idx, uint32_t nq, uint32_t slots) {
+  isl::SearchWorkspace& ws = idx->ws;
+  if (!ws.stream) {
+    ISL_HIP(hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking));
+    ISL_HIP(hipEventCreate(&ws.ev0));
+    ISL_HIP(hipEventCreate(&ws.ev1));
+    ISL_HIP(hipMalloc(&ws.ticket, 16));
+  }
+  if (ws.slots < slots || !ws.ovf_tab) {
+    if (ws.ovf_tab) (void)hipFree(ws.ovf_tab);
+    ws.ovf_tab = nullptr;
+    ws.ovf_bits = kOvfBits;
+    uint64_t n = (uint64_t)slots << kOvfBits;
+    ISL_HIP(hipMalloc(&ws.ovf_tab, n * 4));
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(2048), dim3(256), 0, ws.stream, ws.ovf_tab, n, EMPTY);
+    ISL_HIP(hipGetLastError());
+    ws.slots = slots;
+  }
+  if (ws.cap_q < nq) {
+    void* ptrs[] = {ws.status, ws.payload, ws.ctr, ws.redo};
+    for (void* q : ptrs)
+      if (q) (void)hipFree(q);
+    ws.status = nullptr; ws.payload = nullptr; ws.ctr = nullptr; ws.redo = nullptr;
+    ws.cap_q = 0;
+    uint32_t cap = nq < 1024 ? 1024 : nq;
+    ISL_HIP(hipMalloc(&ws.status, (size_t)cap * 4));
+    ISL_HIP(hipMalloc(&ws.payload, (size_t)cap * 8));
+    ISL_HIP(hipMalloc(&ws.ctr, (size_t)cap * 16));
+    ISL_HIP(hipMalloc(&ws.redo, (size_t)cap * 4));
+    ws.cap_q = cap;
+  }
+  return ISL_OK;
+}
+
+isl_status prepare_exact(const isl_index* idx) {
+  isl::SearchWorkspace& ws = idx->ws;
+  uint64_t max_id = std::max(idx->num_nodes, idx->nvec);
+  uint64_t words = (max_id + 31) / 32 + 1;
+  uint64_t cand_cap = std::min<uint64_t>(max_id + 1, 1ull << 22);
+  uint32_t ucap = std::max<uint32_t>(idx->max_degree, 64);
+  if (ws.exact_slots == kExactSlots && ws.vis_words >= words && ws.cand_cap >= cand_cap &&
+      ws.ulist_cap >= ucap)
+    return ISL_OK;
+  void* ptrs[] = {ws.cand_d, ws.cand_id, ws.vis_bits, ws.ulist};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  ws.cand_d = nullptr; ws.cand_id = nullptr; ws.vis_bits = nullptr; ws.ulist = nullptr;
+  ws.exact_slots = 0;
+  ISL_HIP(hipMalloc(&ws.cand_d, (size_t)kExactSlots * cand_cap * 4));
+  ISL_HIP(hipMalloc(&ws.cand_id, (size_t)kExactSlots * cand_cap * 4));
+  ISL_HIP(hipMalloc(&ws.vis_bits, (size_t)kExactSlots * words * 4));
+  ISL_HIP(hipMalloc(&ws.ulist, (size_t)kExactSlots * ucap * 4));
+  ws.exact_slots = kExactSlots;
+  ws.cand_cap = cand_cap;
+  ws.vis_words = words;
+  ws.ulist_cap = ucap;
+  return ISL_OK;
+}
+
+// Core of both entry points: every pointer is a device pointer.
+isl_status search_device(const isl_index* idx, const float* d_queries, uint64_t nq, uint64_t d,
+                         uint64_t k, uint64_t ef_in, uint64_t* d_ids, float* d_dist,
+                         uint32_t* d_count, hipStream_t user_stream) {
+  isl::SearchWorkspace& ws = idx->ws;
+  const uint32_t ef = (uint32_t)std::max(ef_in, k);  // leann.rs:890
+  if (ef > kMaxExactEf)
+    return isl::fail(ISL_ERR_UNSUPPORTED, "ef = %u exceeds the device limit %u", ef, kMaxExactEf);
+  if (nq > 0x7FFFFFFFull) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "too many queries");
+
+  int ncu = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, idx->device) == hipSuccess) ncu = prop.multiProcessorCount;
+
+  FastGeom fg = fast_geometry(ef, (uint32_t)d);
+  bool use_fast = ef <= 512 && ef >= 1 && idx->max_degree <= 64;
+  uint32_t per_cu = (uint32_t)std::min<size_t>(8, (160 * 1024) / fg.lds);
+  if (per_cu == 0) use_fast = false;
+  uint32_t slots = std::max<uint32_t>(1, (uint32_t)ncu * std::max<uint32_t>(per_cu, 1));
+  ISL_TRY(prepare_workspace(idx, (uint32_t)nq, slots));
+  ISL_TRY(prepare_exact(idx));
+  hipStream_t st = user_stream ? user_stream : ws.stream;
+
+  SearchParams p{};
+  p.off = idx->d_off;
+  p.adj = idx->d_adj;
+  p.num_nodes = idx->num_nodes;
+  p.emb = idx->d_emb;
+  p.nvec = idx->nvec;
+  p.stride = idx->emb_stride;
+  p.d = (uint32_t)d;
+  p.queries = d_queries;
+  p.nq = (uint32_t)nq;
+  p.k = (uint32_t)k;
+  p.ef = ef;
+  p.prune_ratio = idx->cfg.prune_ratio;
+  p.prune_strategy = idx->cfg.pruning_strategy;
+  p.entry = (uint32_t)std::min<uint64_t>(idx->entry_point, 0x7FFFFFF0ull);
+  p.out_ids = d_ids;
+  p.out_dist = d_dist;
+  p.out_count = d_count;
+  p.status = ws.status;
+  p.payload = ws.payload;
+  p.ctr = ws.ctr;
+  p.ticket = ws.ticket;
+  p.redo = ws.redo;
+  p.hbits = fg.hbits;
+  p.otab = ws.ovf_tab;
+  p.obits = ws.ovf_bits;
+  p.cand_d = ws.cand_d;
+  p.cand_id = ws.cand_id;
+  p.cand_cap = ws.cand_cap;
+  p.vis_bits = ws.vis_bits;
+  p.vis_words = ws.vis_words;
+  p.ulist = ws.ulist;
+  p.ulist_cap = ws.ulist_cap;
+
+  ISL_HIP(hipMemsetAsync(ws.ticket, 0, 16, st));
+  ISL_HIP(hipEventRecord(ws.ev0, st));
+  if (use_fast) {
+    uint32_t grid = (uint32_t)std::min<uint64_t>(nq, slots);
+    int S = ef <= 64 ? 1 : ef <= 128 ? 2 : ef <= 256 ? 4 : 8;
+    const int metric = (int)idx->cfg.metric;
+    switch (S) {
+      case 1: launch_fast<1>(metric, grid, fg.lds, st, p); break;
+      case 2: launch_fast<2>(metric, grid, fg.lds, st, p); break;
+      case 4: launch_fast<4>(metric, grid, fg.lds, st, p); break;
+      default: launch_fast<8>(metric, grid, fg.lds, st, p); break;
+    }
+    ISL_HIP(hipGetLastError());
+  } else {
+    // every query goes to the exact kernel: redo = [0, nq)
+    std::vector<uint32_t> all(nq);
+    for (uint64_t i = 0; i < nq; i++) all[i] = (uint32_t)i;
+    uint32_t head[4] = {0, (uint32_t)nq, 0, 0};
+    ISL_HIP(hipMemcpyAsync(ws.redo, all.data(), nq * 4, hipMemcpyHostToDevice, st));
+    ISL_HIP(hipMemcpyAsync(ws.ticket, head, 16, hipMemcpyHostToDevice, st));
+    ISL_HIP(hipStreamSynchronize(st));
+  }
+  {
+    uint32_t grid = (uint32_t)std::min<uint64_t>(nq, ws.exact_slots);
+    launch_exact((int)idx->cfg.metric, grid, exact_lds(ef, (uint32_t)d), st, p);
+    ISL_HIP(hipGetLastError());
+  }
+  ISL_HIP(hipEventRecord(ws.ev1, st));
+
+  std::vector<uint32_t> status(nq), ctr(nq * 4);
+  uint32_t head[4];
+  ISL_HIP(hipMemcpyAsync(status.data(), ws.status, nq * 4, hipMemcpyDeviceToHost, st));
+  ISL_HIP(hipMemcpyAsync(ctr.data(), ws.ctr, nq * 16, hipMemcpyDeviceToHost, st));
+  ISL_HIP(hipMemcpyAsync(head, ws.ticket, 16, hipMemcpyDeviceToHost, st));
+  ISL_HIP(hipStreamSynchronize(st));
+  float ms = 0.0f;
+  (void)hipEventElapsedTime(&ms, ws.ev0, ws.ev1);
+
+  isl_search_stats& ss = idx->stats;
+  ss = isl_search_stats{};
+  ss.queries = nq;
+  ss.exact_path = head[1];
+  ss.kernel_ms = ms;
+  for (uint64_t i = 0; i < nq; i++) {
+    ss.expansions += ctr[i * 4 + 0];
+    ss.edges += ctr[i * 4 + 1];
+    ss.evals += ctr[i * 4 + 2];
+    ss.pushes += ctr[i * 4 + 3];
+  }
+  for (uint64_t i = 0; i < nq; i++) {  // first failing query wins, like the sequential map
+    if (status[i] == QS_OK) continue;
+    if (status[i] == QS_NODE_NOT_FOUND) {
+      uint64_t node = 0;
+      ISL_HIP(hipMemcpy(&node, ws.payload + i, 8, hipMemcpyDeviceToHost));
+      return isl::fail_node(node);
+    }
+    if (status[i] == QS_SCRATCH)
+      return isl::fail(ISL_ERR_SEARCH, "Search error: candidate scratch exhausted for query %llu",
+                       (unsigned long long)i);
+    return isl::fail(ISL_ERR_SEARCH, "Search error: query %llu left in state 0x%x",
+                     (unsigned long long)i, status[i]);
+  }
+  return ISL_OK;
+}
+
+// Checks shared by the entry points; *done = 1 when the call is already answered.
+isl_status precheck(const isl_index* idx, uint64_t nq, uint64_t d, uint64_t k, uint32_t* out_count,
+                    bool count_on_device, int* done) {
+  *done = 0;
+  if (!idx) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "index is NULL");
+  if (nq == 0) { *done = 1; return ISL_OK; }
+  if (idx->num_nodes == 0) {  // is_empty() -> Ok(vec![]), leann.rs:875-877
+    if (out_count) {
+      if (count_on_device) {
+        if (idx->device >= 0) {
+          ISL_TRY(isl::use_device(idx->device));
+          ISL_HIP(hipMemset(out_count, 0, nq * 4));
+        }
+      } else {
+        memset(out_count, 0, nq * 4);
+      }
+    }
+    *done = 1;
+    return ISL_OK;
+  }
+  if (idx->has_dimension && d != idx->dimension)  // leann.rs:880-887
+    return isl::fail_dim(idx->dimension, d);
+  if (!idx->has_entry) return isl::fail(ISL_ERR_INDEX_NOT_BUILT, "Index not built");  // :889
+  if (idx->device < 0 || !idx->d_off)
+    return isl::fail(ISL_ERR_DEVICE, "index is not resident on a device (isl_index_upload)");
+  if (!idx->d_emb)
+    return isl::fail(ISL_ERR_EMBEDDING, "Embedding error: no embedding provider attached");
+  if (d != idx->emb_d)  // metric.calculate length check, distance.rs:39-44
+    return isl::fail_dim(d, idx->emb_d);
+  if (k == 0) {
+    *done = 2;  // nothing to write but counts
+  }
+  return ISL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+isl_status isl_search_batch_device(const isl_index* idx, const float* d_queries, uint64_t nq,
+                                   uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_out_ids,
+                                   float* d_out_dist, uint32_t* d_out_count, void* stream) {
+  int done = 0;
+  ISL_TRY(precheck(idx, nq, d, k, d_out_count, true, &done));
+  if (done == 1) return ISL_OK;
+  if (!d_queries || !d_out_count || (k && (!d_out_ids || !d_out_dist)))
+    return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
+  ISL_TRY(isl::use_device(idx->device));
+  std::lock_guard<std::mutex> lock(idx->mu);
+  return search_device(idx, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count,
+                       (hipStream_t)stream);
+}
+
+isl_status isl_search_batch(const isl_index* idx, const float* queries, uint64_t nq, uint64_t d,
+                            uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dist,
+                            uint32_t* out_count) {
+  int done = 0;
+  ISL_TRY(precheck(idx, nq, d, k, out_count, false, &done));
+  if (done == 1) return ISL_OK;
+  if (!queries || !out_count || (k && (!out_ids || !out_dist)))
+    return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
+  ISL_TRY(isl::use_device(idx->device));
+  std::lock_guard<std::mutex> lock(idx->mu);
+  isl::SearchWorkspace& ws = idx->ws;
+  uint64_t qbytes = nq * d * 4;
+  if (ws.q_stage_bytes < qbytes) {
+    if (ws.q_stage) (void)hipFree(ws.q_stage);
+    ws.q_stage = nullptr;
+    ws.q_stage_bytes = 0;
+    ISL_HIP(hipMalloc(&ws.q_stage, qbytes));
+    ws.q_stage_bytes = qbytes;
+  }
+  uint64_t slots = nq * std::max<uint64_t>(k, 1);
+  if (ws.out_stage_slots < slots) {
+    void* ptrs[] = {ws.ids_stage, ws.dist_stage, ws.count_stage};
+    for (void* q : ptrs)
+      if (q) (void)hipFree(q);
+    ws.ids_stage = nullptr; ws.dist_stage = nullptr; ws.count_stage = nullptr;
+    ws.out_stage_slots = 0;
+    ISL_HIP(hipMalloc(&ws.ids_stage, slots * 8));
+    ISL_HIP(hipMalloc(&ws.dist_stage, slots * 4));
+    ISL_HIP(hipMalloc(&ws.count_stage, slots * 4));
+    ws.out_stage_slots = slots;
+  }
+  ISL_HIP(hipMemcpy(ws.q_stage, queries, qbytes, hipMemcpyHostToDevice));
+  ISL_TRY(search_device(idx, ws.q_stage, nq, d, k, ef, ws.ids_stage, ws.dist_stage,
+                        ws.count_stage, nullptr));
+  if (k) {
+    ISL_HIP(hipMemcpy(out_ids, ws.ids_stage, nq * k * 8, hipMemcpyDeviceToHost));
+    ISL_HIP(hipMemcpy(out_dist, ws.dist_stage, nq * k * 4, hipMemcpyDeviceToHost));
+  }
+  ISL_HIP(hipMemcpy(out_count, ws.count_stage, nq * 4, hipMemcpyDeviceToHost));
+  return ISL_OK;
+}
+
+isl_status isl_search(const isl_index* idx, const float* query, uint64_t d, uint64_t k,
+                      uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
+  if (!idx) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "index is NULL");
+  return isl_search_batch(idx, query, 1, d, k, idx->cfg.ef_search, out_ids, out_dist,
+                          out_count);  // leann.rs:858-865
+}
+
+isl_status isl_search_last_stats(const isl_index* idx, isl_search_stats* out) {
+  if (!idx || !out) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL argument");
+  std::lock_guard<std::mutex> lock(idx->mu);
+  *out = idx->stats;
+  return ISL_OK;
+}
+
+}  // extern "C"

@@ -41,3 +41,29 @@ def random_csr(n, deg, seed, dup=False):
         else:
             nb[int(off[i]):int(off[i + 1])] = rng.choice(n, size=min(k, n), replace=False)[:k]
     return off, nb
+
+
+def knn_graph(x, deg, seed=0, extra_random=4):
+    """Brute-force cosine kNN digraph + a few random long-range edges, as CSR (u64).
+    Test infrastructure only: gives the traversal a realistic graph at a few 10k nodes."""
+    n = x.shape[0]
+    rng = np.random.default_rng(seed)
+    xn = x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-30)
+    k = min(deg - extra_random, n - 1)
+    nbrs = np.empty((n, k), dtype=np.int64)
+    step = 2048
+    for s in range(0, n, step):
+        sim = xn[s:s + step] @ xn.T
+        sim[np.arange(sim.shape[0]), np.arange(s, min(s + step, n))] = -np.inf
+        part = np.argpartition(-sim, k - 1, axis=1)[:, :k]
+        order = np.argsort(-np.take_along_axis(sim, part, 1), axis=1)
+        nbrs[s:s + step] = np.take_along_axis(part, order, 1)
+    rows = []
+    for i in range(n):
+        row = list(dict.fromkeys(nbrs[i].tolist()))
+        extra = [int(v) for v in rng.integers(0, n, size=extra_random) if v != i and v not in row]
+        rows.append(row + extra)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in rows])
+    nb = np.fromiter((v for r in rows for v in r), dtype=np.uint64, count=int(off[-1]))
+    return off, nb

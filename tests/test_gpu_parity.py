@@ -1,0 +1,329 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Integer/ID outputs must match exactly; distances are required to be
+BIT-IDENTICAL (the kernels keep the reference's f32 operation order), which is stricter
+than the 1e-5 the north star asks for."""
+import numpy as np
+import pytest
+
+import islands_amd as ia
+from _data import clustered_vectors, knn_graph, random_csr, random_levels, uniform_vectors
+
+pytestmark = pytest.mark.gpu
+
+METRICS = [ia.DistanceMetric.Cosine, ia.DistanceMetric.Euclidean, ia.DistanceMetric.DotProduct,
+           ia.DistanceMetric.Manhattan]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def make_index(orc_csr, vectors, cfg=None, dimension=-1):
+    g = ia.CsrGraph(node_offsets=orc_csr.node_offsets, neighbors=orc_csr.neighbors,
+                    levels=orc_csr.levels, entry_point=orc_csr.entry_point,
+                    max_level=orc_csr.max_level, num_nodes=orc_csr.num_nodes,
+                    degree_counts=orc_csr.degree_counts)
+    d = vectors.shape[1] if dimension == -1 else dimension
+    idx = ia.LeannIndex.from_csr(g, cfg, dimension=d)
+    idx.upload(0)
+    idx.set_embeddings(vectors)
+    return idx
+
+
+def assert_same_search(orc, idx, csr, vectors, queries, k, ef, **okw):
+    ids, dist, cnt = idx.search_batch(queries, k, ef)
+    st = idx.last_stats()
+    tot = {"expansions": 0, "edges": 0, "evals": 0, "pushes": 0}
+    for i, q in enumerate(queries):
+        r = orc.leann_search(csr, vectors, q, k, ef, **okw)
+        assert r.status == 0
+        n = int(cnt[i])
+        assert n == r.ids.size, (i, n, r.ids.size)
+        assert ids[i, :n].tolist() == r.ids.tolist(), (i, ids[i, :n], r.ids)
+        assert bits(dist[i, :n]).tolist() == bits(r.dist).tolist(), (i, dist[i, :n], r.dist)
+        for f in tot:
+            tot[f] += r.counters[f]
+    return st, tot
+
+
+# ---------------------------------------------------------------- distance.rs
+def test_distance_kats():  # distance.rs:150-261, 354-372
+    C, E, D, M = METRICS
+    assert abs(ia.calculate(C, [1, 2, 3], [1, 2, 3])) < 1e-6
+    assert abs(ia.calculate(C, [1, 0], [0, 1]) - 1) < 1e-6
+    assert abs(ia.calculate(C, [1, 0], [-1, 0]) - 2) < 1e-6
+    assert abs(ia.calculate(E, [1, 2, 3], [1, 2, 3])) < 1e-6
+    assert abs(ia.calculate(E, [0, 0], [3, 4]) - 5) < 1e-6
+    assert ia.calculate(E, [1, 0], [0, 1]) == np.float32(1.414213562373095)
+    assert ia.calculate(M, [1, 1], [1, 1]) == 0.0 and ia.calculate(M, [0, 0], [3, 4]) == 7.0
+    assert ia.calculate(C, [0, 0, 0], [1, 2, 3]) == 1.0
+    assert abs(ia.calculate(D, [1, 2, 3], [4, 5, 6]) + 32) < 1e-6
+    assert abs(ia.calculate_squared(E, [0, 0], [3, 4]) - 25) < 1e-6
+    d = ia.calculate(C, [1, 0], [0, 1])
+    assert abs(ia.calculate_squared(C, [1, 0], [0, 1]) - d * d) < 1e-6
+    b = ia.batch_calculate(C, [1, 0], [[1, 0], [0, 1], [-1, 0]])
+    assert abs(b[0]) < 1e-6 and abs(b[1] - 1) < 1e-6 and abs(b[2] - 2) < 1e-6
+    assert ia.batch_calculate(C, [1, 0], np.zeros((0, 2), np.float32)).size == 0
+    for m in METRICS:
+        with pytest.raises(ia.CoreError) as e:
+            ia.calculate(m, [1, 2], [1, 2, 3])
+        assert e.value.kind == "DimensionMismatch"
+    with pytest.raises(ia.CoreError):
+        ia.calculate_squared(E, [1, 2], [1, 2, 3])
+
+
+@pytest.mark.parametrize("d", [1, 3, 5, 63, 64, 65, 128, 255, 768, 1000])
+def test_batch_distance_bit_exact(orc, d):
+    rng = np.random.default_rng(d)
+    q = rng.standard_normal(d).astype(np.float32)
+    rows = rng.standard_normal((131, d)).astype(np.float32)
+    rows[7] = 0.0
+    rows[9] = q
+    for m in METRICS:
+        got = ia.batch_calculate(m, q, rows)
+        exp = orc.batch_distance(int(m), q, rows)
+        assert bits(got).tolist() == bits(exp).tolist(), (m, d)
+
+
+def test_sqrt_div_correctly_rounded(orc):
+    """Euclidean ends in sqrtf and cosine in a division: both must be IEEE-correct on gfx950."""
+    rng = np.random.default_rng(5)
+    rows = (rng.standard_normal((4096, 8)) * np.exp(rng.uniform(-20, 20, (4096, 1)))).astype(np.float32)
+    q = rng.standard_normal(8).astype(np.float32)
+    for m in (ia.DistanceMetric.Euclidean, ia.DistanceMetric.Cosine):
+        assert bits(ia.batch_calculate(m, q, rows)).tolist() == \
+            bits(orc.batch_distance(int(m), q, rows)).tolist()
+
+
+def test_normalize_rows(orc):  # distance.rs:231-248
+    rng = np.random.default_rng(2)
+    rows = rng.standard_normal((70, 32)).astype(np.float32)
+    rows[3] = 0
+    got = ia.normalize_rows(rows)
+    for i in range(rows.shape[0]):
+        assert bits(got[i]).tolist() == bits(orc.normalize(rows[i])).tolist()
+    v = ia.normalize_rows([[3.0, 4.0, 0.0, 0.0]])[0]
+    assert abs(float(np.sqrt((v * v).sum())) - 1) < 1e-6
+
+
+# -------------------------------------------------------------------- search
+def test_reference_search_tests(orc):
+    """leann.rs:1290-1343, 1515-1531 restated against the HIP path."""
+    v = uniform_vectors(100, 16, 42)
+    csr = orc.leann_build(v, levels=random_levels(100, 30, 43))
+    idx = make_index(csr, v)
+    res = idx.search(v[0], 5, ia.InMemoryEmbeddingProvider(v))
+    assert len(res) == 5 and res[0][0] == 0 and res[0][1] < 0.01
+    res = idx.search_with_params([0.5] * 16, 10, 64)
+    assert all(res[i][1] <= res[i + 1][1] for i in range(len(res) - 1))
+    with pytest.raises(ia.CoreError) as e:  # leann.rs:1315-1325
+        idx.search_with_params([0.5] * 8, 5, 64)
+    assert e.value.kind == "DimensionMismatch" and (e.value.expected, e.value.actual) == (16, 8)
+    for n, d in ((10, 8), (50, 16), (100, 32)):
+        vv = uniform_vectors(n, d, 42)
+        c2 = orc.leann_build(vv, levels=random_levels(n, 30, 1))
+        i2 = make_index(c2, vv)
+        assert len(i2.search(vv[0], min(5, n))) == min(5, n)
+
+
+def test_empty_index_and_not_built():
+    idx = ia.LeannIndex.with_defaults()  # leann.rs:1306-1313
+    ids, dist, cnt = idx.search_batch(np.full((3, 8), 0.5, np.float32), 5, 64)
+    assert cnt.tolist() == [0, 0, 0]
+    g = ia.CsrGraph(node_offsets=np.array([0, 0], np.uint64), num_nodes=1, entry_point=None,
+                    levels=np.zeros(1, np.uint64), degree_counts=np.zeros(1, np.uint64))
+    i2 = ia.LeannIndex.from_csr(g, dimension=4).upload(0)
+    i2.set_embeddings(np.ones((1, 4), np.float32))
+    with pytest.raises(ia.CoreError) as e:  # leann.rs:889
+        i2.search_with_params([1, 2, 3, 4], 1, 4)
+    assert e.value.kind == "IndexNotBuilt"
+
+
+@pytest.mark.parametrize("ef", [1, 8, 64, 100, 128, 200, 300, 600])
+def test_search_matches_oracle_built_graph(orc, ef):
+    n, d = 400, 24
+    v = uniform_vectors(n, d, 7)
+    csr = orc.leann_build(v, m=8, m0=16, ef_construction=40, levels=random_levels(n, 8, 8))
+    idx = make_index(csr, v, ia.LeannConfig(m=8, m0=16, ef_construction=40))
+    queries = np.concatenate([uniform_vectors(20, d, 9), v[:4], np.full((1, d), 0.5, np.float32)])
+    st, tot = assert_same_search(orc, idx, csr, v, queries, min(10, ef), ef)
+    for f in ("expansions", "edges", "evals", "pushes"):
+        assert st[f] == tot[f], (f, st, tot)
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_search_all_metrics(orc, metric):
+    n, d = 300, 20
+    v = uniform_vectors(n, d, 11)
+    csr = orc.leann_build(v, m=8, m0=16, ef_construction=40, metric=int(metric),
+                          levels=random_levels(n, 8, 12))
+    idx = make_index(csr, v, ia.LeannConfig(m=8, m0=16, ef_construction=40, metric=metric))
+    assert_same_search(orc, idx, csr, v, uniform_vectors(16, d, 13), 10, 48, metric=int(metric))
+
+
+@pytest.mark.parametrize("strategy", [ia.PruningStrategy.Global, ia.PruningStrategy.Local])
+@pytest.mark.parametrize("ratio", [0.3, 0.5, 0.8])
+def test_search_with_pruning(orc, strategy, ratio):  # leann.rs:1437-1464, 1553-1572
+    n, d = 200, 16
+    v = uniform_vectors(n, d, 21)
+    csr = orc.leann_build(v, m=8, m0=16, ef_construction=40, levels=random_levels(n, 8, 22))
+    cfg = ia.LeannConfig(m=8, m0=16, ef_construction=40, prune_ratio=ratio,
+                         pruning_strategy=strategy)
+    idx = make_index(csr, v, cfg)
+    assert_same_search(orc, idx, csr, v, uniform_vectors(12, d, 23), 5, 32,
+                       prune_ratio=ratio, strategy=int(strategy))
+    assert len(idx.search_with_params(v[0], 5, 64)) == 5
+
+
+def test_ties_duplicates_and_dup_rows_take_exact_path(orc):
+    """Duplicated vectors give exact distance ties; duplicated ids inside adjacency rows are
+    always 'already visited' on their second occurrence.  IDs must still match the oracle's
+    BinaryHeap-order tie-breaking."""
+    for seed, dup_rows in ((0, False), (1, True)):
+        n, d = 240, 12
+        v = uniform_vectors(n, d, 30 + seed)
+        v[n // 2:] = v[: n - n // 2]
+        off, nb = random_csr(n, 12, 40 + seed, dup=dup_rows)
+        csr = orc.Csr(off, nb, entry_point=5)
+        idx = make_index(csr, v)
+        queries = uniform_vectors(24, d, 50 + seed)
+        for ef in (4, 16, 64, 130):
+            st, _ = assert_same_search(orc, idx, csr, v, queries, min(10, ef), ef)
+        assert st["exact_path"] > 0
+
+
+def test_long_rows_use_exact_kernel(orc):  # LeannConfig::accurate(): m0 = 96 > 64 lanes
+    n, d = 300, 16
+    v = uniform_vectors(n, d, 60)
+    off, nb = random_csr(n, 96, 61)
+    csr = orc.Csr(off, nb, entry_point=0)
+    idx = make_index(csr, v, ia.LeannConfig.accurate())
+    st, _ = assert_same_search(orc, idx, csr, v, uniform_vectors(8, d, 62), 10, 128)
+    assert st["exact_path"] == 8
+
+
+def test_node_not_found_and_unreachable(orc):
+    v = uniform_vectors(3, 4, 0)
+    csr = orc.Csr(node_offsets=[0, 1, 2, 2], neighbors=[1, 0], entry_point=0)
+    idx = make_index(csr, v)
+    res = idx.search_with_params([0.1] * 4, 3, 8)  # node 2 unreachable -> fewer than k
+    assert sorted(r[0] for r in res) == [0, 1]
+    bad = orc.Csr(node_offsets=[0, 1, 1], neighbors=[7], entry_point=0)
+    i2 = make_index(bad, uniform_vectors(2, 4, 0))
+    with pytest.raises(ia.CoreError) as e:  # provider miss, leann.rs:145-150
+        i2.search_with_params([0.1] * 4, 1, 4)
+    assert e.value.kind == "NodeNotFound" and e.value.node == 7
+    # graph smaller than the provider: ids >= num_nodes have vectors but no adjacency
+    v5 = uniform_vectors(5, 4, 1)
+    g2 = orc.Csr(node_offsets=[0, 2, 3], neighbors=[1, 4, 3], entry_point=0)
+    i3 = make_index(g2, v5)
+    assert_same_search(orc, i3, g2, v5, uniform_vectors(3, 4, 2), 5, 8)
+
+
+def test_bincode_roundtrip_then_search(orc):  # leann.rs:1347-1364
+    n, d = 120, 16
+    v = uniform_vectors(n, d, 70)
+    csr = orc.leann_build(v, levels=random_levels(n, 30, 71))
+    idx = make_index(csr, v)
+    restored = ia.LeannIndex.from_bytes(idx.to_bytes())
+    assert len(restored) == len(idx) and restored.dimension() == idx.dimension()
+    restored.upload(0).set_embeddings(v)
+    q = uniform_vectors(6, d, 72)
+    a = idx.search_batch(q, 5, 64)
+    b = restored.search_batch(q, 5, 64)
+    assert a[0].tolist() == b[0].tolist() and bits(a[1]).tolist() == bits(b[1]).tolist()
+
+
+def test_mid_size_d768_matches_oracle(orc):
+    """BASELINE config 1 shape (10k nodes, d=768, M=30, efSearch=64) plus ef=128."""
+    n, d = 10000, 768
+    v = clustered_vectors(n, d, 80, per_cluster=100)
+    off, nb = knn_graph(v, 60, seed=81)
+    csr = orc.Csr(off, nb, entry_point=0)
+    idx = make_index(csr, v)
+    queries = clustered_vectors(48, d, 82, per_cluster=4)
+    for ef in (64, 128):
+        st, tot = assert_same_search(orc, idx, csr, v, queries, 10, ef)
+        for f in ("expansions", "edges", "evals"):
+            assert st[f] == tot[f]
+
+
+def test_device_born_csr_and_device_buffers(orc):
+    torch = pytest.importorskip("torch")
+    n, d = 2000, 64
+    v = clustered_vectors(n, d, 90)
+    off, nb = knn_graph(v, 24, seed=91)
+    csr = orc.Csr(off, nb, entry_point=17)
+    dev = torch.device("cuda:0")
+    t_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    t_nb = torch.from_numpy(nb.astype(np.int64)).to(torch.int32).to(dev)
+    t_v = torch.from_numpy(v).to(dev)
+    idx = ia.LeannIndex.from_device_csr(t_off.data_ptr(), t_nb.data_ptr(), n, 17, d)
+    idx.set_embeddings(None, device_ptr=t_v.data_ptr(), n=n, d=d)
+    q = clustered_vectors(32, d, 92)
+    t_q = torch.from_numpy(q).to(dev)
+    k, ef = 10, 64
+    o_ids = torch.zeros((32, k), dtype=torch.int64, device=dev)
+    o_dist = torch.zeros((32, k), dtype=torch.float32, device=dev)
+    o_cnt = torch.zeros(32, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    idx.search_batch_device(t_q.data_ptr(), 32, d, k, ef, o_ids.data_ptr(), o_dist.data_ptr(),
+                            o_cnt.data_ptr())
+    for i in range(32):
+        r = orc.leann_search(csr, v, q[i], k, ef)
+        assert o_ids[i].cpu().numpy().tolist() == r.ids.tolist()
+        assert bits(o_dist[i].cpu().numpy()).tolist() == bits(r.dist).tolist()
+    # host CSR is materialised lazily from the device copy
+    assert idx.get_neighbors(5).tolist() == csr.get_neighbors(5)
+    assert ia.LeannIndex.from_bytes(idx.to_bytes()).get_neighbors(9).tolist() == csr.get_neighbors(9)
+
+
+# ----------------------------------------------------------------- search.rs
+def test_merge_topk_matches_multi_index_searcher(orc):  # search.rs:211-237
+    rng = np.random.default_rng(3)
+    nl, nq, k = 4, 9, 6
+    scores = np.sort(rng.integers(0, 8, (nl, nq, k)).astype(np.float32) / 4, axis=2)
+    ids = rng.integers(0, 1000, (nl, nq, k)).astype(np.uint64)
+    counts = rng.integers(0, k + 1, (nl, nq)).astype(np.uint32)
+    base = np.array([0, 1000, 2000, 3000], np.uint64)
+    oi, osc, osrc, oc = ia.merge_topk(ids, scores, counts, 10, id_base=base)
+    for q in range(nq):
+        lists_i = [ids[l, q, :counts[l, q]] + base[l] for l in range(nl)]
+        lists_s = [scores[l, q, :counts[l, q]] for l in range(nl)]
+        st, ei, es, esrc = orc.multi_index_merge(lists_i, lists_s, 10)
+        n = int(oc[q])
+        assert n == ei.size and oi[q, :n].tolist() == ei.tolist()
+        assert osrc[q, :n].tolist() == esrc.tolist() and bits(osc[q, :n]).tolist() == bits(es).tolist()
+
+
+# --------------------------------------------------------------------- pq.rs
+def test_pq_matches_oracle(orc):  # pq.rs:639-677, 787-809, 505-520
+    rng = np.random.default_rng(4)
+    for (m, K, dsub) in ((8, 256, 16), (4, 37, 5), (64, 256, 64)):
+        d = m * dsub
+        cb = rng.standard_normal((m, K, dsub)).astype(np.float32)
+        pq = ia.ProductQuantizer(d, cb)
+        vecs = rng.standard_normal((40, d)).astype(np.float32)
+        vecs[:K if K < 40 else 40] = cb[:, :min(K, 40)].transpose(1, 0, 2).reshape(-1, d)[:40]
+        q = rng.standard_normal((3, d)).astype(np.float32)
+        codes = pq.encode(vecs)
+        for i in range(vecs.shape[0]):
+            assert codes[i].tolist() == orc.pq_encode(orc.EUCLIDEAN, cb, vecs[i])[1].tolist()
+        tabs = pq.build_distance_tables(q)
+        for i in range(3):
+            assert bits(tabs[i]).tolist() == bits(orc.pq_build_tables(cb, q[i])[1]).tolist()
+        td = pq.table_distance(tabs[0], codes)
+        ad = pq.asymmetric_distance(q[0], codes)
+        for i in range(vecs.shape[0]):
+            assert bits(td[i:i + 1])[0] == bits([orc.pq_table_distance(tabs[0], codes[i])])[0]
+            assert bits(ad[i:i + 1])[0] == bits([orc.pq_asymmetric_distance(cb, q[0], codes[i])[1]])[0]
+        assert np.all(np.abs(td - ad) < 1e-3)
+    pq8 = ia.ProductQuantizer(128, np.zeros((8, 256, 16), np.float32))
+    assert pq8.compression_ratio() == 64.0 and pq8.bytes_per_vector() == 8
+    assert ia.ProductQuantizer(128, np.zeros((8, 300, 16), np.float32)).bytes_per_vector() == 16
+    with pytest.raises(ia.CoreError) as e:
+        pq8.table_distance(np.zeros((8, 256), np.float32), np.full((1, 8), 300, np.uint16))
+    assert e.value.kind == "PQError"
+    with pytest.raises(ia.CoreError) as e:
+        pq8.build_distance_tables(np.zeros(64, np.float32))
+    assert e.value.kind == "DimensionMismatch"
