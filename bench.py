@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the LEANN search hot path on MI355X.
+
+Metric (BASELINE.json): queries/sec at recall@10 >= 0.95 on synthetic 10M x 768 vectors,
+ef = 128, k = 10, query batch 1024, embeddings resident in HBM (in-memory provider).
+One "step" = one pass of the hot path (isl_search_batch_device) over one batch of queries
+that is already resident in HBM.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU (N > 1), mode "shard" (default, the north star's layout): the index is sharded by
+node-id range, every rank searches the whole query batch in its own sub-graph, the
+per-shard top-k are exchanged with one RCCL all-gather and merged by isl_merge_topk
+(MultiIndexSearcher::search semantics, src/core/search.rs:211-237).  Total index size and
+query count are fixed as N grows -> "strong" scaling.  Mode "replica": every rank holds the
+full index and answers its own batch, no data-path collective -> "weak".
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def algorithmic_bytes(st: dict, d: int, k: int, elem: int = 4) -> float:
+    """V*d*s + 4*E + 8*H + 4*d + 12*k per query, summed over a batch."""
+    return (st["evals"] * d * elem + 4 * st["edges"] + 8 * st["expansions"] +
+            st["queries"] * (4 * d + 12 * k))
+
+
+def cpu_baseline(x, offsets, neighbours, entry, queries, k, ef, budget_s=25.0):
+    """Times the CPU oracle (the restated reference algorithm) on this box's host cores.
+    The oracle is only the checker / baseline here, never the measured product."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+
+    orc.build()
+    t0 = time.time()
+    xv = x.cpu().numpy()
+    off = offsets.cpu().numpy().astype(np.uint64)
+    nb = neighbours.cpu().numpy().astype(np.uint64)
+    csr = orc.Csr(off, nb, entry_point=entry)
+    q = queries.cpu().numpy()
+    log(f"cpu_baseline: host copy of the index took {time.time() - t0:.1f}s")
+    # calibrate on a few queries, then size the sample to the time budget
+    t0 = time.time()
+    for i in range(4):
+        orc.leann_search(csr, xv, q[i], k, ef, copy_per_node=True)
+    per_q = (time.time() - t0) / 4
+    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    threads = max(1, min(ncores, 64))
+    n1 = int(max(8, min(q.shape[0], (budget_s / 2) / max(per_q, 1e-6))))
+    t0 = time.time()
+    for i in range(n1):
+        orc.leann_search(csr, xv, q[i], k, ef, copy_per_node=True)
+    qps_1 = n1 / (time.time() - t0)
+    nm = int(max(threads, min(q.shape[0], (budget_s / 2) * qps_1 * threads * 0.7)))
+
+    def work(lo, hi):
+        for i in range(lo, hi):
+            orc.leann_search(csr, xv, q[i % q.shape[0]], k, ef, copy_per_node=True)
+
+    bounds = np.linspace(0, nm, threads + 1).astype(int)
+    ths = [threading.Thread(target=work, args=(bounds[t], bounds[t + 1])) for t in range(threads)]
+    t0 = time.time()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    qps_m = nm / (time.time() - t0)
+    return {
+        "value": round(qps_m, 2), "unit": "queries/s", "cores": threads, "kind": "port",
+        "value_1thread": round(qps_1, 2),
+        "sample": f"{nm} queries of the same batch on {threads} threads (queries statically "
+                  f"partitioned; ctypes releases the GIL), {n1} queries on 1 thread; "
+                  "copy-per-node provider as in leann.rs:145-154; same graph, ef and k",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nodes", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--nq", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--ef", type=int, default=128)
+    ap.add_argument("--per-cluster", type=int, default=1000)
+    ap.add_argument("--mode", choices=["shard", "replica"], default="shard")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--distinct-batches", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    import islands_amd as ia
+    from islands_amd import synth
+
+    N, d, nq, k, ef = args.nodes, args.dim, args.nq, args.k, args.ef
+    shard_mode = world > 1 and args.mode == "shard"
+    if shard_mode:
+        lo = rank * N // world
+        hi = (rank + 1) * N // world
+    else:
+        lo, hi = 0, N
+    n_local = hi - lo
+
+    # ---------------- setup (untimed): data, graph, index upload, queries, ground truth
+    t0 = time.time()
+    x = synth.make_rows(N, d, lo, n_local, per_cluster=args.per_cluster, device=dev)
+    torch.cuda.synchronize()
+    log(f"rows [{lo},{hi}) generated in {time.time() - t0:.1f}s")
+    t0 = time.time()
+    offsets, neighbours, entry = synth.build_graph(x, m0=60)
+    torch.cuda.synchronize()
+    gst = synth.graph_stats(offsets)
+    log(f"graph built in {time.time() - t0:.1f}s: {gst}")
+    t0 = time.time()
+    cfg = ia.LeannConfig.paper_default()
+    idx = ia.LeannIndex.from_device_csr(offsets.data_ptr(), neighbours.data_ptr(), n_local, entry,
+                                        d, cfg, device=local_rank)
+    idx.set_embeddings(None, device_ptr=x.data_ptr(), n=n_local, d=d)
+    log(f"index resident in {time.time() - t0:.1f}s")
+
+    nb_batches = max(1, min(args.distinct_batches, args.steps + args.warmup))
+    qsets, truths = [], []
+    for b in range(nb_batches):
+        # replica mode: every rank answers its own batches; shard mode: same batch on all ranks
+        qoff = (b + (rank * nb_batches if (world > 1 and not shard_mode) else 0)) * nq
+        q = synth.make_rows(N, d, qoff, nq, per_cluster=args.per_cluster, device=dev, query=True)
+        qsets.append(q.contiguous())
+        ti, td = synth.brute_force_topk(x, q, k)
+        truths.append((ti + lo, td))
+    torch.cuda.synchronize()
+
+    out_ids = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+    out_dist = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+    out_cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+    if shard_mode:
+        g_ids = torch.zeros((world, nq, k), dtype=torch.int64, device=dev)
+        g_dist = torch.zeros((world, nq, k), dtype=torch.float32, device=dev)
+        g_cnt = torch.zeros((world, nq), dtype=torch.int32, device=dev)
+        m_ids = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+        m_dist = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+        m_src = torch.zeros((nq, k), dtype=torch.int32, device=dev)
+        m_cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+        id_base = np.array([r * N // world for r in range(world)], dtype=np.uint64)
+        # exact global truth = merge of the per-shard exact top-k (same collective + merge)
+        g_truth = []
+        for (ti, td) in truths:
+            gi = [torch.zeros_like(ti) for _ in range(world)]
+            gd = [torch.zeros_like(td) for _ in range(world)]
+            dist.all_gather(gi, ti.contiguous())
+            dist.all_gather(gd, td.contiguous())
+            ci, cd = torch.cat(gi, 1), torch.cat(gd, 1)
+            sel = torch.topk(cd, k, dim=1, largest=False).indices
+            g_truth.append(torch.gather(ci, 1, sel))
+
+    import ctypes as C
+    from islands_amd import _ffi
+
+    def step(b):
+        q = qsets[b % nb_batches]
+        idx.search_batch_device(q.data_ptr(), nq, d, k, ef, out_ids.data_ptr(),
+                                out_dist.data_ptr(), out_cnt.data_ptr())
+        st = idx.last_stats()
+        if shard_mode:
+            # the one exchange step of the path: per-shard top-k over xGMI (RCCL all-gather)
+            dist.all_gather_into_tensor(g_ids, out_ids)
+            dist.all_gather_into_tensor(g_dist, out_dist)
+            dist.all_gather_into_tensor(g_cnt, out_cnt)
+            torch.cuda.synchronize()
+            ia._check(_ffi.lib().isl_merge_topk(
+                world, nq, k, C.c_void_p(g_ids.data_ptr()), C.c_void_p(g_dist.data_ptr()),
+                C.c_void_p(g_cnt.data_ptr()), id_base.ctypes.data_as(C.c_void_p), k,
+                C.c_void_p(m_ids.data_ptr()), C.c_void_p(m_dist.data_ptr()),
+                C.c_void_p(m_src.data_ptr()), C.c_void_p(m_cnt.data_ptr()), 1, local_rank, None))
+        return st
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        step(w)
+    barrier()
+    t0 = time.perf_counter()
+    agg = {"queries": 0, "expansions": 0, "edges": 0, "evals": 0, "pushes": 0, "exact_path": 0,
+           "kernel_ms": 0.0}
+    recalls = []
+    for s in range(args.steps):
+        st = step(args.warmup + s)
+        for f in agg:
+            agg[f] += st[f]
+        if s < nb_batches:  # recall is checked outside the clock below; keep results of a few steps
+            b = (args.warmup + s) % nb_batches
+            if shard_mode:
+                recalls.append((b, m_ids.clone(), m_cnt.clone()))
+            else:
+                recalls.append((b, out_ids.clone(), out_cnt.clone()))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    rec = []
+    for (b, ids_b, cnt_b) in recalls:
+        truth = g_truth[b] if shard_mode else truths[b][0]
+        rec.append(synth.recall_at_k(ids_b, cnt_b, truth))
+    recall = float(np.mean(rec)) if rec else 0.0
+
+    queries_per_step = nq if (world == 1 or shard_mode) else nq * world
+    value = queries_per_step * args.steps / elapsed
+    kernel_ms = agg["kernel_ms"] / max(args.steps, 1)
+    bytes_per_launch = algorithmic_bytes(agg, d, k) / max(args.steps, 1)
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic_env = os.environ.get("ISL_TRAFFIC_BYTES")
+
+    result = {
+        "metric": "queries/sec @ recall@10>=0.95, 10Mx768 ef=128",
+        "value": round(value, 2),
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "strong" if (world == 1 or shard_mode) else "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "recall_at_10": round(recall, 4),
+        "config": {
+            "workload": f"{N} x {d} f32 rows resident in HBM (in-memory provider), hierarchical "
+                        f"Gaussian mixture, graph deg<= 60 (mean {gst['deg_mean']:.1f}), "
+                        f"query batch {nq}, k={k}, ef={ef}, cosine",
+            "nodes": N, "dim": d, "query_batch": nq, "k": k, "ef": ef,
+            "parallelism": ("single" if world == 1 else
+                            (f"shard{world}: node-id ranges, RCCL all-gather + top-k merge"
+                             if shard_mode else f"replica{world}")),
+            "per_query": {"expansions": round(agg["expansions"] / max(agg["queries"], 1), 1),
+                          "edges": round(agg["edges"] / max(agg["queries"], 1), 1),
+                          "evals": round(agg["evals"] / max(agg["queries"], 1), 1)},
+            "exact_path_queries": agg["exact_path"],
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": float(traffic_env) if traffic_env else None,
+            "kernel": "leann_search_fast<2,cosine> (+ exact kernel for tie queries)",
+            "kernel_ms": round(kernel_ms, 3),
+            "algorithmic_bytes_per_launch": round(bytes_per_launch, 0),
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline(x, offsets, neighbours, entry, qsets[0], k, ef)
+        except Exception as e:  # the baseline must never take the measured number down with it
+            result["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0,
+                                      "kind": "port", "sample": f"failed: {e!r}"}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -61,8 +61,10 @@ def knn_graph(x, deg, seed=0, extra_random=4):
     rows = []
     for i in range(n):
         row = list(dict.fromkeys(nbrs[i].tolist()))
-        extra = [int(v) for v in rng.integers(0, n, size=extra_random) if v != i and v not in row]
-        rows.append(row + extra)
+        for v in rng.integers(0, n, size=extra_random):
+            if int(v) != i and int(v) not in row:
+                row.append(int(v))
+        rows.append(row)
     off = np.zeros(n + 1, dtype=np.uint64)
     off[1:] = np.cumsum([len(r) for r in rows])
     nb = np.fromiter((v for r in rows for v in r), dtype=np.uint64, count=int(off[-1]))
