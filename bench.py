@@ -220,7 +220,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     agg = {"queries": 0, "expansions": 0, "edges": 0, "evals": 0, "pushes": 0, "exact_path": 0,
-           "kernel_ms": 0.0}
+           "replayed": 0, "kernel_ms": 0.0}
     recalls = []
     for s in range(args.steps):
         st = step(args.warmup + s)
@@ -277,7 +277,7 @@ def main():
             "per_query": {"expansions": round(agg["expansions"] / max(agg["queries"], 1), 1),
                           "edges": round(agg["edges"] / max(agg["queries"], 1), 1),
                           "evals": round(agg["evals"] / max(agg["queries"], 1), 1)},
-            "exact_path_queries": agg["exact_path"],
+            "exact_path_queries": agg["exact_path"], "replayed_queries": agg["replayed"],
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

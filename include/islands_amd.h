@@ -176,6 +176,7 @@ typedef struct isl_search_stats {
   uint64_t evals;          /* V: embeddings fetched / distances evaluated */
   uint64_t pushes;         /* heap insertions */
   uint64_t exact_path;     /* queries answered by the heap-exact kernel */
+  uint64_t replayed;       /* queries whose tied prefix was re-ordered by the replay kernel */
   double kernel_ms;        /* HIP-event time of the search kernels of that call */
 } isl_search_stats;
 isl_status isl_search_last_stats(const isl_index* idx, isl_search_stats* out);

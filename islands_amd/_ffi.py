@@ -28,7 +28,7 @@ class LeannConfigC(C.Structure):
 
 class SearchStatsC(C.Structure):
     _fields_ = [("queries", u64), ("expansions", u64), ("edges", u64), ("evals", u64),
-                ("pushes", u64), ("exact_path", u64), ("kernel_ms", C.c_double)]
+                ("pushes", u64), ("exact_path", u64), ("replayed", u64), ("kernel_ms", C.c_double)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/islands_amd.h
@@ -100,6 +100,14 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C islands_amd/csrc` (there is no CPU fallback)")
+        # PyTorch wheels bundle their own HIP runtime.  When torch is used in the same process
+        # (device tensors handed to the *_device entry points, torch.distributed) it must be the
+        # first to load it, otherwise torch later finds "No HIP GPUs".  torch stays optional.
+        if os.environ.get("ISL_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the library does not export it

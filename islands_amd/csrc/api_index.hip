@@ -58,7 +58,7 @@ isl_status use_device(int32_t device) {
 }
 
 void free_workspace(SearchWorkspace& ws) {
-  void* ptrs[] = {ws.ovf_tab, ws.status,  ws.payload,   ws.ctr,        ws.ticket,     ws.redo,
+  void* ptrs[] = {ws.ovf_tab, ws.status,  ws.payload,   ws.ctr,        ws.ticket,     ws.redo, ws.replay, ws.plog,
                   ws.cand_d,  ws.cand_id, ws.vis_bits,  ws.ulist,      ws.q_stage,    ws.ids_stage,
                   ws.dist_stage, ws.count_stage};
   for (void* p : ptrs)

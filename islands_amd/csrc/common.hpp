@@ -54,6 +54,9 @@ struct SearchWorkspace {
   uint32_t* ctr = nullptr;     // [cap_q][4]  H,E,V,pushes
   uint32_t* ticket = nullptr;  // work-queue heads (fast, exact)
   uint32_t* redo = nullptr;    // [cap_q] query ids routed to the exact kernel
+  uint32_t* replay = nullptr;  // [cap_q] query ids routed to the replay kernel
+  uint64_t* plog = nullptr;    // [cap_q][plog_cap] push log (distance bits, id)
+  uint64_t plog_entries = 0;
   // exact-kernel scratch
   uint32_t exact_slots = 0;
   uint64_t cand_cap = 0;       // entries per slot in the candidate heap

@@ -40,7 +40,8 @@ enum : uint32_t {
   QS_OK = 0,
   QS_NODE_NOT_FOUND = 5,
   QS_REDO = 0x100,     // fast kernel gave up -> exact kernel
-  QS_SCRATCH = 0x101   // exact kernel ran out of candidate scratch
+  QS_SCRATCH = 0x101,  // exact kernel ran out of candidate scratch
+  QS_REPLAY = 0x102    // result-heap order needed: replay kernel re-orders from the push log
 };
 
 struct SearchParams {
@@ -63,8 +64,12 @@ struct SearchParams {
   uint32_t* status;
   uint64_t* payload;
   uint32_t* ctr;     // [nq][4]
-  uint32_t* ticket;  // [0] fast queue head, [1] redo count, [2] exact queue head
-  uint32_t* redo;    // [nq]
+  uint32_t* ticket;  // [0] fast head, [1] redo count, [2] exact head, [3] replay count,
+                     // [4] replay head, [8..11] why the fast kernel gave a query up
+  uint32_t* redo;    // [nq] queries for the exact kernel
+  uint32_t* replay;  // [nq] queries for the replay kernel
+  uint2* plog;       // [nq][plog_cap] (distance bits, id) of every results.push, in order
+  uint32_t plog_cap;
   uint32_t hbits;    // LDS visited table: 1 << hbits entries
   uint32_t* otab;    // overflow visited table in HBM, per slot
   uint32_t obits;
@@ -186,6 +191,11 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
     uint32_t status = QS_OK;
     uint64_t payload = 0;
     uint32_t cH = 0, cE = 0, cV = 0, cP = 0;
+    // Tie-evicted candidates: entries pushed out of R whose distance
+    // equals the new worst distance stay poppable in the reference's candidate heap.  Lane i <
+    // tcount holds one id; they all share the current worst distance and die when it drops.
+    uint32_t t_id = 0, tcount = 0;
+    uint2* plog = p.plog + (size_t)qi * p.plog_cap;
 
     // entry point: provider.compute_embedding(entry) + distance, leann.rs:911-916
     if ((uint64_t)p.entry >= p.nvec) {
@@ -198,6 +208,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       if (lane == 0) htab[hslot(p.entry, p.hbits)] = p.entry;
       hcount = 1;
       rs.insert(ed, p.entry);
+      if (lane == 0) plog[0] = make_uint2(__float_as_uint(ed), p.entry);
       cP = 1;
       __syncthreads();
     }
@@ -206,16 +217,33 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       // candidates.pop(): the smallest unexpanded key of R (leann.rs:922); when none is
       // left every remaining candidate is farther than the worst result -> break (:924-928)
       uint32_t e = rs.first_unexpanded();
-      if (e == 0xFFFFFFFFu) break;
-      uint32_t cid = rs.id_at(e) & ID_MASK;
-      rs.mark_expanded(e);
+      uint32_t cid;
+      if (e != 0xFFFFFFFFu) {
+        cid = rs.id_at(e) & ID_MASK;
+        rs.mark_expanded(e);
+      } else if (tcount > 0) {
+        // every key of R is expanded; the next candidates are the tie-evicted ones, whose
+        // distance equals the worst result (`dist > worst` is false, leann.rs:925): smallest id first
+        uint32_t best = rl_u(t_id, 0);
+        int bl = 0;
+        for (uint32_t i = 1; i < tcount; ++i) {
+          uint32_t v = rl_u(t_id, (int)i);
+          if (v < best) { best = v; bl = (int)i; }
+        }
+        uint32_t last = rl_u(t_id, (int)(tcount - 1));
+        if (lane == bl) t_id = last;
+        tcount -= 1;
+        cid = best;
+      } else {
+        break;
+      }
       if ((uint64_t)cid >= p.num_nodes) continue;  // get_neighbors -> None, leann.rs:227-229
       uint64_t o0 = p.off[cid], o1 = p.off[cid + 1];
       uint32_t deg = (uint32_t)(o1 - o0);
       cH += 1;
       cE += deg;
       if (deg == 0) continue;
-      if (deg > 64) { status = QS_REDO; break; }  // long rows: exact kernel
+      if (deg > 64) { status = QS_REDO; payload = 1; break; }  // long rows: exact kernel
       bool active = (uint32_t)lane < deg;
       uint32_t nid = active ? p.adj[o0 + lane] : EMPTY;
 
@@ -255,7 +283,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       if (!ovf) hcount += nu;
       else {
         ocount += nu;
-        if (ocount > olimit) { status = QS_REDO; break; }
+        if (ocount > olimit) { status = QS_REDO; payload = 2; break; }
       }
       if (nu == 0) continue;  // leann.rs:939-941
 
@@ -289,14 +317,26 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
         int r = __ffsll((long long)pm) - 1;
         float id_d = rl_f(nd, r);
         uint32_t id_i = rl_u(uid, r);
+        if (cP < p.plog_cap) {
+          if (lane == 0) plog[cP] = make_uint2(__float_as_uint(id_d), id_i);
+        }
         if (full) {
-          // results.push + pop: the old worst leaves.  It stays in the reference's candidate
-          // heap; that only matters if it ties with the new worst.
+          // results.push + pop: the old worst leaves R but stays in the reference's candidate
+          // heap.  It can only be popped again while its distance still equals the worst one.
           float old_worst = worst;
+          uint32_t old_raw = rs.id_at(ef - 1);
           rs.insert(id_d, id_i);
           rs.len = ef;
           float new_worst = rs.dist_at(ef - 1);
-          if (ordkey(old_worst) == ordkey(new_worst)) status = QS_REDO;
+          if (ordkey(old_worst) != ordkey(new_worst)) {
+            tcount = 0;
+          } else if (!(old_raw & FLAG_EXP)) {
+            if (tcount >= 64) { status = QS_REDO; payload = 3; }
+            else {
+              if (lane == (int)tcount) t_id = old_raw & ID_MASK;
+              tcount += 1;
+            }
+          }
         } else {
           rs.insert(id_d, id_i);
         }
@@ -323,7 +363,10 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
         }
         if (e + 1 < chk && ordkey(rs.d[s]) == ordkey(nxt)) tie = true;
       }
-      if (ballot(tie)) status = QS_REDO;
+      if (ballot(tie)) {
+        if (cP <= p.plog_cap) status = QS_REPLAY;
+        else { status = QS_REDO; payload = 4; }
+      }
     }
     if (status == QS_OK) {
 #pragma unroll
@@ -343,7 +386,13 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       p.ctr[qi * 4 + 1] = cE;
       p.ctr[qi * 4 + 2] = cV;
       p.ctr[qi * 4 + 3] = cP;
-      if (status == QS_REDO) p.redo[atomicAdd(&p.ticket[1], 1u)] = qi;
+      if (status == QS_REDO) {
+        p.redo[atomicAdd(&p.ticket[1], 1u)] = qi;
+        // why: 1 long row, 2 visited overflow, 3 tie-candidate overflow, 0 push-log overflow
+        atomicAdd(&p.ticket[8 + ((uint32_t)payload & 3u)], 1u);
+      } else if (status == QS_REPLAY) {
+        p.replay[atomicAdd(&p.ticket[3], 1u)] = qi;
+      }
     }
     if (ovf) {  // leave the overflow table empty for the next query of this slot
       for (uint32_t i = lane; i < ocap; i += 64) otab[i] = EMPTY;
@@ -614,6 +663,76 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
   }
 }
 
+// ---------------------------------------------------------------- replay kernel
+// The fast kernel's result SET is exact; only the ORDER of equal distances in the returned
+// prefix depends on Rust's BinaryHeap array layout (results.into_iter() + stable sort,
+// leann.rs:984-986).  For the few queries where such a tie shows up, this kernel replays the
+// logged sequence of results.push (and the pop that follows each push beyond ef) on an exact
+// BinaryHeap emulation and re-emits the prefix in the reference's order.  No graph or row
+// traffic: one wave per query, lane 0 sifts in LDS.
+__global__ __launch_bounds__(64) void leann_replay_order(SearchParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const uint32_t ef = p.ef;
+  float* res_d = reinterpret_cast<float*>(smem);
+  uint32_t* res_i = reinterpret_cast<uint32_t*>(res_d + (ef + 1));
+  uint2* stage = reinterpret_cast<uint2*>(((uintptr_t)(res_i + (ef + 1)) + 15) & ~(uintptr_t)15);
+  uint32_t* s_len = reinterpret_cast<uint32_t*>(stage + 64);
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&p.ticket[4], 1u);
+    t = uni(t);
+    uint32_t nrep = *((volatile uint32_t*)&p.ticket[3]);
+    if (t >= nrep) break;
+    const uint32_t qi = p.replay[t];
+    const uint32_t npush = p.ctr[qi * 4 + 3];
+    const uint2* plog = p.plog + (size_t)qi * p.plog_cap;
+    uint64_t rlen = 0;
+    for (uint32_t base = 0; base < npush; base += 64) {
+      if (base + lane < npush) stage[lane] = plog[base + lane];
+      __syncthreads();
+      if (lane == 0) {
+        uint32_t cnt = npush - base < 64 ? npush - base : 64;
+        for (uint32_t i = 0; i < cnt; ++i) {
+          heap_push<ResultOrder>(res_d, res_i, rlen, __uint_as_float(stage[i].x), stage[i].y);
+          if (rlen > ef) {
+            float dd;
+            uint32_t di;
+            heap_pop<ResultOrder>(res_d, res_i, rlen, dd, di);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (lane == 0) {
+      for (uint64_t i = 1; i < rlen; ++i) {  // stable sort by distance (partial_cmp == Less moves)
+        float d = res_d[i];
+        uint32_t id = res_i[i];
+        uint64_t j = i;
+        while (j > 0 && d < res_d[j - 1]) {
+          res_d[j] = res_d[j - 1];
+          res_i[j] = res_i[j - 1];
+          j--;
+        }
+        res_d[j] = d;
+        res_i[j] = id;
+      }
+      *s_len = (uint32_t)rlen;
+    }
+    __syncthreads();
+    uint32_t outn = *s_len < p.k ? *s_len : p.k;
+    for (uint32_t e = lane; e < outn; e += 64) {
+      p.out_ids[(uint64_t)qi * p.k + e] = (uint64_t)res_i[e];
+      p.out_dist[(uint64_t)qi * p.k + e] = res_d[e];
+    }
+    if (lane == 0) {
+      p.status[qi] = QS_OK;
+      p.out_count[qi] = outn;
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------ launchers
 struct FastGeom {
   uint32_t hbits;
@@ -681,13 +800,13 @@ isl_status ensure(T*& ptr, uint64_t& have, uint64_t want) {
   return ISL_OK;
 }
 
-isl_status prepare_workspace(const isl_index* idx, uint32_t nq, uint32_t slots) {
+isl_status prepare_workspace(const isl_index* idx, uint32_t nq, uint32_t slots, uint32_t plog_cap) {
   isl::SearchWorkspace& ws = idx->ws;
   if (!ws.stream) {
     ISL_HIP(hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking));
     ISL_HIP(hipEventCreate(&ws.ev0));
     ISL_HIP(hipEventCreate(&ws.ev1));
-    ISL_HIP(hipMalloc(&ws.ticket, 16));
+    ISL_HIP(hipMalloc(&ws.ticket, 64));
   }
   if (ws.slots < slots || !ws.ovf_tab) {
     if (ws.ovf_tab) (void)hipFree(ws.ovf_tab);
@@ -700,17 +819,27 @@ isl_status prepare_workspace(const isl_index* idx, uint32_t nq, uint32_t slots) 
     ws.slots = slots;
   }
   if (ws.cap_q < nq) {
-    void* ptrs[] = {ws.status, ws.payload, ws.ctr, ws.redo};
+    void* ptrs[] = {ws.status, ws.payload, ws.ctr, ws.redo, ws.replay};
     for (void* q : ptrs)
       if (q) (void)hipFree(q);
     ws.status = nullptr; ws.payload = nullptr; ws.ctr = nullptr; ws.redo = nullptr;
+    ws.replay = nullptr;
     ws.cap_q = 0;
     uint32_t cap = nq < 1024 ? 1024 : nq;
     ISL_HIP(hipMalloc(&ws.status, (size_t)cap * 4));
     ISL_HIP(hipMalloc(&ws.payload, (size_t)cap * 8));
     ISL_HIP(hipMalloc(&ws.ctr, (size_t)cap * 16));
     ISL_HIP(hipMalloc(&ws.redo, (size_t)cap * 4));
+    ISL_HIP(hipMalloc(&ws.replay, (size_t)cap * 4));
     ws.cap_q = cap;
+  }
+  uint64_t want_log = (uint64_t)ws.cap_q * plog_cap;
+  if (ws.plog_entries < want_log) {
+    if (ws.plog) (void)hipFree(ws.plog);
+    ws.plog = nullptr;
+    ws.plog_entries = 0;
+    ISL_HIP(hipMalloc(&ws.plog, want_log * 8));
+    ws.plog_entries = want_log;
   }
   return ISL_OK;
 }
@@ -759,7 +888,8 @@ isl_status search_device(const isl_index* idx, const float* d_queries, uint64_t 
   uint32_t per_cu = (uint32_t)std::min<size_t>(8, (160 * 1024) / fg.lds);
   if (per_cu == 0) use_fast = false;
   uint32_t slots = std::max<uint32_t>(1, (uint32_t)ncu * std::max<uint32_t>(per_cu, 1));
-  ISL_TRY(prepare_workspace(idx, (uint32_t)nq, slots));
+  const uint32_t plog_cap = std::max<uint32_t>(1024, 12 * ef);  // pushes per query ~ 3-6 x ef
+  ISL_TRY(prepare_workspace(idx, (uint32_t)nq, slots, plog_cap));
   ISL_TRY(prepare_exact(idx));
   hipStream_t st = user_stream ? user_stream : ws.stream;
 
@@ -786,6 +916,9 @@ isl_status search_device(const isl_index* idx, const float* d_queries, uint64_t 
   p.ctr = ws.ctr;
   p.ticket = ws.ticket;
   p.redo = ws.redo;
+  p.replay = ws.replay;
+  p.plog = reinterpret_cast<uint2*>(ws.plog);
+  p.plog_cap = plog_cap;
   p.hbits = fg.hbits;
   p.otab = ws.ovf_tab;
   p.obits = ws.ovf_bits;
@@ -797,7 +930,7 @@ isl_status search_device(const isl_index* idx, const float* d_queries, uint64_t 
   p.ulist = ws.ulist;
   p.ulist_cap = ws.ulist_cap;
 
-  ISL_HIP(hipMemsetAsync(ws.ticket, 0, 16, st));
+  ISL_HIP(hipMemsetAsync(ws.ticket, 0, 64, st));
   ISL_HIP(hipEventRecord(ws.ev0, st));
   if (use_fast) {
     uint32_t grid = (uint32_t)std::min<uint64_t>(nq, slots);
@@ -810,13 +943,19 @@ isl_status search_device(const isl_index* idx, const float* d_queries, uint64_t 
       default: launch_fast<8>(metric, grid, fg.lds, st, p); break;
     }
     ISL_HIP(hipGetLastError());
+    {
+      size_t rlds = (size_t)(ef + 1) * 8 + 16 + 64 * 8 + 16;
+      uint32_t rgrid = (uint32_t)std::min<uint64_t>(nq, 256);
+      launch_one(leann_replay_order, rgrid, rlds, st, p);
+      ISL_HIP(hipGetLastError());
+    }
   } else {
     // every query goes to the exact kernel: redo = [0, nq)
     std::vector<uint32_t> all(nq);
     for (uint64_t i = 0; i < nq; i++) all[i] = (uint32_t)i;
-    uint32_t head[4] = {0, (uint32_t)nq, 0, 0};
+    uint32_t head0[4] = {0, (uint32_t)nq, 0, 0};
     ISL_HIP(hipMemcpyAsync(ws.redo, all.data(), nq * 4, hipMemcpyHostToDevice, st));
-    ISL_HIP(hipMemcpyAsync(ws.ticket, head, 16, hipMemcpyHostToDevice, st));
+    ISL_HIP(hipMemcpyAsync(ws.ticket, head0, 16, hipMemcpyHostToDevice, st));
     ISL_HIP(hipStreamSynchronize(st));
   }
   {
@@ -827,10 +966,10 @@ isl_status search_device(const isl_index* idx, const float* d_queries, uint64_t 
   ISL_HIP(hipEventRecord(ws.ev1, st));
 
   std::vector<uint32_t> status(nq), ctr(nq * 4);
-  uint32_t head[4];
+  uint32_t head[16];
   ISL_HIP(hipMemcpyAsync(status.data(), ws.status, nq * 4, hipMemcpyDeviceToHost, st));
   ISL_HIP(hipMemcpyAsync(ctr.data(), ws.ctr, nq * 16, hipMemcpyDeviceToHost, st));
-  ISL_HIP(hipMemcpyAsync(head, ws.ticket, 16, hipMemcpyDeviceToHost, st));
+  ISL_HIP(hipMemcpyAsync(head, ws.ticket, 64, hipMemcpyDeviceToHost, st));
   ISL_HIP(hipStreamSynchronize(st));
   float ms = 0.0f;
   (void)hipEventElapsedTime(&ms, ws.ev0, ws.ev1);
@@ -839,12 +978,19 @@ isl_status search_device(const isl_index* idx, const float* d_queries, uint64_t 
   ss = isl_search_stats{};
   ss.queries = nq;
   ss.exact_path = head[1];
+  ss.replayed = head[3];
   ss.kernel_ms = ms;
   for (uint64_t i = 0; i < nq; i++) {
     ss.expansions += ctr[i * 4 + 0];
     ss.edges += ctr[i * 4 + 1];
     ss.evals += ctr[i * 4 + 2];
     ss.pushes += ctr[i * 4 + 3];
+  }
+  if (getenv("ISL_DEBUG") && (head[1] || head[3])) {
+    fprintf(stderr, "[isl] %u of %llu queries re-run by the exact kernel (fast kernel %s): "
+            "long-row %u, visited-overflow %u, tie-candidate overflow %u, push-log overflow %u; "
+            "%u re-ordered by the replay kernel\n", head[1], (unsigned long long)nq,
+            use_fast ? "on" : "off", head[9], head[10], head[11], head[8], head[3]);
   }
   for (uint64_t i = 0; i < nq; i++) {  // first failing query wins, like the sequential map
     if (status[i] == QS_OK) continue;
