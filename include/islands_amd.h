@@ -159,7 +159,8 @@ isl_status isl_search_batch(const isl_index* idx, const float* queries, uint64_t
                             uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dist,
                             uint32_t* out_count);
 /* Same with every buffer already on the index's device; enqueued on `stream`
- * and synchronised before returning (status needs the result). */
+ * (NULL = the legacy default stream, i.e. ordered after the caller's earlier
+ * default-stream work) and synchronised before returning (status needs the result). */
 isl_status isl_search_batch_device(const isl_index* idx, const float* d_queries, uint64_t nq,
                                    uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_out_ids,
                                    float* d_out_dist, uint32_t* d_out_count, void* stream);

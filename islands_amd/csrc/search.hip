@@ -816,6 +816,7 @@ isl_status prepare_workspace(const isl_index* idx, uint32_t nq, uint32_t slots, 
     ISL_HIP(hipMalloc(&ws.ovf_tab, n * 4));
     hipLaunchKernelGGL(fill_u32_kernel, dim3(2048), dim3(256), 0, ws.stream, ws.ovf_tab, n, EMPTY);
     ISL_HIP(hipGetLastError());
+    ISL_HIP(hipStreamSynchronize(ws.stream));
     ws.slots = slots;
   }
   if (ws.cap_q < nq) {
@@ -872,7 +873,7 @@ isl_status prepare_exact(const isl_index* idx) {
 // Core of both entry points: every pointer is a device pointer.
 isl_status search_device(const isl_index* idx, const float* d_queries, uint64_t nq, uint64_t d,
                          uint64_t k, uint64_t ef_in, uint64_t* d_ids, float* d_dist,
-                         uint32_t* d_count, hipStream_t user_stream) {
+                         uint32_t* d_count, hipStream_t user_stream, bool use_own_stream) {
   isl::SearchWorkspace& ws = idx->ws;
   const uint32_t ef = (uint32_t)std::max(ef_in, k);  // leann.rs:890
   if (ef > kMaxExactEf)
@@ -891,7 +892,9 @@ isl_status search_device(const isl_index* idx, const float* d_queries, uint64_t 
   const uint32_t plog_cap = std::max<uint32_t>(1024, 12 * ef);  // pushes per query ~ 3-6 x ef
   ISL_TRY(prepare_workspace(idx, (uint32_t)nq, slots, plog_cap));
   ISL_TRY(prepare_exact(idx));
-  hipStream_t st = user_stream ? user_stream : ws.stream;
+  // device entry point: NULL means the legacy default stream, which is ordered after the
+  // caller's earlier work on it (e.g. torch kernels that produced the queries)
+  hipStream_t st = use_own_stream ? ws.stream : user_stream;
 
   SearchParams p{};
   p.off = idx->d_off;
@@ -1058,7 +1061,7 @@ isl_status isl_search_batch_device(const isl_index* idx, const float* d_queries,
   ISL_TRY(isl::use_device(idx->device));
   std::lock_guard<std::mutex> lock(idx->mu);
   return search_device(idx, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count,
-                       (hipStream_t)stream);
+                       (hipStream_t)stream, false);
 }
 
 isl_status isl_search_batch(const isl_index* idx, const float* queries, uint64_t nq, uint64_t d,
@@ -1094,7 +1097,7 @@ isl_status isl_search_batch(const isl_index* idx, const float* queries, uint64_t
   }
   ISL_HIP(hipMemcpy(ws.q_stage, queries, qbytes, hipMemcpyHostToDevice));
   ISL_TRY(search_device(idx, ws.q_stage, nq, d, k, ef, ws.ids_stage, ws.dist_stage,
-                        ws.count_stage, nullptr));
+                        ws.count_stage, nullptr, true));
   if (k) {
     ISL_HIP(hipMemcpy(out_ids, ws.ids_stage, nq * k * 8, hipMemcpyDeviceToHost));
     ISL_HIP(hipMemcpy(out_dist, ws.dist_stage, nq * k * 4, hipMemcpyDeviceToHost));

@@ -8,12 +8,15 @@ O(n * ef_c * deg * d) CPU loop); a native HIP builder that follows the reference
 selection rule is SURVEY.md section 8f rank 1 ("next").
 
 Dataset "H" (hierarchical Gaussian mixture, L2-normalised) -- SURVEY section 8d's dataset G
-with one more level so that a proximity graph is navigable at all: with i.i.d. N(0, I)
-centres in d = 768 every centre is (almost) equidistant from every other, so best-first
-search has no gradient to follow between 10^4 clusters.
-    super-centres  s ~ N(0, I_d)                    one per 100 leaf clusters
-    leaf centres   c = s + 0.5 * N(0, I_d)          one per `per_cluster` points
+made hierarchical so that a proximity graph is navigable at all: with 10^4 i.i.d. N(0, I)
+centres in d = 768 every centre is (almost) equidistant from every other and best-first
+search has no gradient to follow between clusters.  Here the N / per_cluster leaf centres are
+the leaves of a tree with branching factor 10 (depth 4 at 10M points); every tree node adds
+an independent Gaussian offset whose scale shrinks with depth (1, 0.7, 0.5, 0.35, ...):
+    leaf centre    c = sum_j SIGMAS[j] * g_j(ancestor_j)
     points         x = c + 0.25 * N(0, I_d), then x / ||x||
+Cosine distance is ~0.03 inside a leaf, ~0.10 / 0.23 / 0.48 / 1.0 to leaves that split off
+1 / 2 / 3 / 4 levels higher.
 Point i belongs to leaf cluster perm(i) // per_cluster for a fixed pseudo-random
 permutation, so neighbouring ids are unrelated.  Every chunk of 65536 rows has its own
 seed: any id range (shard) can be generated independently and identically on any rank.
@@ -35,15 +38,25 @@ def _leaf_of(ids: torch.Tensor, n_total: int, per_cluster: int) -> torch.Tensor:
     return h % n_leaf
 
 
+BRANCH = 10                              # children per internal centre of the mixture tree
+SIGMAS = (1.0, 0.7, 0.5, 0.35, 0.25, 0.2)  # spread added at tree depth 0, 1, 2, ...
+POINT_SIGMA = 0.25
+
+
 def _centres(n_total: int, d: int, per_cluster: int, seed: int, device) -> torch.Tensor:
+    """Leaf centres of the mixture tree: leaf l = sum over depths j of SIGMAS[j] * g_j(l // B^(L-1-j)),
+    g_j ~ N(0, I_d) per tree node, L = number of base-BRANCH digits of the leaf count."""
     n_leaf = max(1, n_total // per_cluster)
-    n_super = max(1, n_leaf // 100)
+    depth = max(1, math.ceil(math.log(n_leaf, BRANCH) - 1e-9)) if n_leaf > 1 else 1
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    sup = torch.randn((n_super, d), generator=g, device=device, dtype=torch.float32)
-    leaf_sup = torch.arange(n_leaf, device=device) % n_super
-    leaf = sup[leaf_sup] + 0.5 * torch.randn((n_leaf, d), generator=g, device=device,
-                                             dtype=torch.float32)
+    leaf_idx = torch.arange(n_leaf, device=device)
+    leaf = torch.zeros((n_leaf, d), device=device, dtype=torch.float32)
+    for j in range(depth):
+        anc = leaf_idx // (BRANCH ** (depth - 1 - j))
+        n_nodes = int(anc.max().item()) + 1
+        table = torch.randn((n_nodes, d), generator=g, device=device, dtype=torch.float32)
+        leaf += SIGMAS[min(j, len(SIGMAS) - 1)] * table[anc]
     return leaf
 
 
@@ -66,7 +79,7 @@ def make_rows(n_total: int, d: int, start: int, count: int, seed: int = 42,
             leaf = torch.randint(0, centres.shape[0], (CHUNK,), generator=g, device=dev)
         else:
             leaf = _leaf_of(ids, n_total, per_cluster)
-        x = centres[leaf] + 0.25 * noise
+        x = centres[leaf] + POINT_SIGMA * noise
         x = x / x.norm(dim=1, keepdim=True)
         a, b = max(lo, start), min(hi, start + count)
         out[a - start:b - start] = x[a - lo:b - lo]
@@ -177,20 +190,77 @@ def _knn_in_buckets(x, member_ids, bucket_off, k, mem_budget=1.5e9):
 
 
 @torch.no_grad()
-def _knn_subset(x, ids, k, centroids_ids=None, assign_chunk=1 << 18):
+def _knn_exact(x, ids, k, chunk=4096):
+    """Exact cosine kNN among the points `ids` (rows L2-normalised), row-chunked GEMM + top-k.
+    Returns int64 [len(ids), k] GLOBAL ids sorted by decreasing similarity."""
+    n = ids.numel()
+    X = x[ids]
+    out = torch.empty((n, k), dtype=torch.int64, device=x.device)
+    for s0 in range(0, n, chunk):
+        sim = X[s0:s0 + chunk] @ X.T
+        r = torch.arange(s0, min(n, s0 + chunk), device=x.device)
+        sim[r - s0, r] = -3.0
+        out[s0:s0 + chunk] = ids[torch.topk(sim, k, dim=1).indices]
+    return out
+
+
+@torch.no_grad()
+def _medoids(x, ids, C, chunk=1 << 18):
+    """For every centroid the most similar point among `ids` (global ids, duplicates removed)."""
+    dev = x.device
+    k = C.shape[0]
+    best_s = torch.full((k,), -3.0, device=dev)
+    best_i = torch.zeros(k, dtype=torch.int64, device=dev)
+    Ch = C.to(torch.bfloat16)
+    for s0 in range(0, ids.numel(), chunk):
+        sub = ids[s0:s0 + chunk]
+        sim = (x[sub].to(torch.bfloat16) @ Ch.T).float()
+        sv, si = sim.max(0)
+        upd = sv > best_s
+        best_s = torch.where(upd, sv, best_s)
+        best_i = torch.where(upd, sub[si], best_i)
+    return torch.unique(best_i)
+
+
+@torch.no_grad()
+def _lloyd_centroids(x, n_cent, iters=3, seed=11, chunk=1 << 18, ids=None):
+    """n_cent unit-norm centroids of the rows `ids` (default: all): random rows refined by a few
+    spherical k-means steps (bf16 assignment GEMM, f32 update)."""
+    dev = x.device
+    if ids is not None:
+        x = x[ids]
+    n, d = x.shape
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    C = x[torch.randperm(n, generator=g, device=dev)[:n_cent]].clone()
+    for _ in range(iters):
+        Ch = C.to(torch.bfloat16)
+        sums = torch.zeros_like(C)
+        cnt = torch.zeros(n_cent, device=dev)
+        for s0 in range(0, n, chunk):
+            xb = x[s0:s0 + chunk]
+            a = torch.argmax(xb.to(torch.bfloat16) @ Ch.T, dim=1)
+            sums.index_add_(0, a, xb)
+            cnt.index_add_(0, a, torch.ones_like(a, dtype=torch.float32))
+        alive = cnt > 0
+        newC = sums / sums.norm(dim=1, keepdim=True).clamp_min(1e-20)
+        C = torch.where(alive[:, None], newC, C)
+    return C
+
+
+@torch.no_grad()
+def _knn_subset(x, ids, k, centroids=None, assign_chunk=1 << 18, exact_limit=400_000):
     """k nearest neighbours (cosine; rows are assumed L2-normalised) among the points `ids`.
-    Small sets: brute force.  Large sets: every point joins the buckets of its 2 nearest
-    centroids, kNN inside buckets, lists merged.  Returns int64 [len(ids), k] of GLOBAL ids
-    (-1 = none)."""
+    Up to exact_limit points: exact.  Larger sets: every point joins the buckets of its 2
+    nearest centroids (`centroids`: [C, d] unit vectors), kNN inside buckets, lists merged.
+    Returns int64 [len(ids), k] of GLOBAL ids (-1 = none), nearest first."""
     dev = x.device
     n = ids.numel()
     if n <= 1:
         return torch.full((n, k), -1, dtype=torch.int64, device=dev)
-    if n <= 32768 or centroids_ids is None:
-        off = torch.tensor([0, n], dtype=torch.int64, device=dev)
-        nb, _ = _knn_in_buckets(x, ids, off, k)
-        return nb
-    C = x[centroids_ids]
+    if n <= exact_limit or centroids is None:
+        return _knn_exact(x, ids, min(k, n - 1))
+    C = centroids
     a1 = torch.empty(n, dtype=torch.int64, device=dev)
     a2 = torch.empty(n, dtype=torch.int64, device=dev)
     Ch = C.to(torch.bfloat16)
@@ -262,12 +332,13 @@ def _diversify(x, ids, cand, m, chunk=8192):
 
 
 @torch.no_grad()
-def _nearest_parent(x, child_ids, parent_ids, chunk=1 << 16):
-    """Index (into parent_ids) of the most similar parent of every child."""
+def _nearest_parent(x, child_ids, parent_ids, npar=2, chunk=1 << 16):
+    """Indices (into parent_ids) of the npar most similar parents of every child: [n, npar]."""
     P = x[parent_ids]
-    out = torch.empty(child_ids.numel(), dtype=torch.int64, device=x.device)
+    npar = min(npar, parent_ids.numel())
+    out = torch.empty((child_ids.numel(), npar), dtype=torch.int64, device=x.device)
     for s0 in range(0, child_ids.numel(), chunk):
-        out[s0:s0 + chunk] = torch.argmax(x[child_ids[s0:s0 + chunk]] @ P.T, dim=1)
+        out[s0:s0 + chunk] = torch.topk(x[child_ids[s0:s0 + chunk]] @ P.T, npar, dim=1).indices
     return out
 
 
@@ -290,20 +361,38 @@ def build_graph(x: torch.Tensor, m0: int = 60, k0: int = 28, k_upper: int = 16, 
     n = x.shape[0]
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
+    # Levels: level 1 is a random 1/level_ratio sample; from level 2 up the nodes are the
+    # medoids of a spherical k-means over the level below, so that every region of the data
+    # owns a node at every scale (a purely random sample leaves ~1/e of the natural
+    # clusters without a representative two levels up, and those become unreachable).
+    exact_limit = 400_000
+    all_ids = torch.arange(n, device=dev)
     perm = torch.randperm(n, generator=g, device=dev)
-    levels = [torch.sort(perm).values]
-    cur = perm
-    while cur.numel() > k_upper:
-        cur = cur[: max(1, cur.numel() // level_ratio)]
-        levels.append(torch.sort(cur).values)
+    cent = None
+    levels = [all_ids]
+    if n > k_upper:
+        n1 = max(1, n // level_ratio)
+        n2 = max(1, n1 // level_ratio)
+        uppers = []
+        if n2 > k_upper // 2:
+            cent = _lloyd_centroids(x, n2)
+            cur = _medoids(x, all_ids, cent)
+            uppers.append(cur)
+            while cur.numel() > k_upper:
+                kk = max(1, cur.numel() // level_ratio)
+                c = _lloyd_centroids(x, kk, iters=5, ids=cur)
+                cur = _medoids(x, cur, c)
+                uppers.append(cur)
+        l1 = perm[:n1]
+        if uppers:
+            l1 = torch.unique(torch.cat([l1, uppers[0]]))
+        levels.append(torch.sort(l1).values)
+        levels.extend(uppers)
+    if n <= exact_limit:
+        cent = None
     top_level_of = torch.zeros(n, dtype=torch.int64, device=dev)
     for li, lv in enumerate(levels):
         top_level_of[lv] = li
-    cent = None  # centroids of the bucketed kNN: the coarsest level with ~n/1024 nodes
-    for lv in levels:
-        if lv.numel() <= max(64, n // 768):
-            cent = lv
-            break
     E_src, E_dst, E_prio = [], [], []
 
     def add_edges(src, dst, prio):
@@ -315,36 +404,57 @@ def build_graph(x: torch.Tensor, m0: int = 60, k0: int = 28, k_upper: int = 16, 
     for li, ids in enumerate(levels):
         if ids.numel() < 2:
             continue
-        use_cent = cent if (cent is not None and ids.numel() > 8 * cent.numel()) else None
+        use_cent = cent
         if li == 0:
-            nb = _knn_subset(x, ids, min(k0, ids.numel() - 1), use_cent)
+            nb = _knn_subset(x, ids, min(k0, ids.numel() - 1), use_cent, exact_limit=exact_limit)
         elif ids.numel() <= k_upper + 1:  # top level: clique
             nb = ids[None, :].expand(ids.numel(), ids.numel()).clone()
             nb[nb == ids[:, None]] = -1
         else:
-            cand = _knn_subset(x, ids, min(pool, ids.numel() - 1), use_cent)
+            cand = _knn_subset(x, ids, min(pool, ids.numel() - 1), use_cent, exact_limit=exact_limit)
             nb = _diversify(x, ids, cand, min(k_upper, cand.shape[1]))
         src = ids[:, None].expand_as(nb).reshape(-1)
         rank = torch.arange(nb.shape[1], device=dev)[None, :].expand_as(nb).reshape(-1)
-        if li == 0:
-            base = torch.full_like(rank, 200)
+        if li == 0:  # upper-level nodes keep their row for navigation: their kNN list goes last
+            upper = (top_level_of[ids] >= 2)[:, None].expand_as(nb).reshape(-1)
+            base = torch.where(upper, torch.full_like(rank, 900), torch.full_like(rank, 200))
         else:  # the node's own top level ranks before its kNN list, lower levels after it
             is_top = (top_level_of[ids] == li)[:, None].expand_as(nb).reshape(-1)
             base = torch.where(is_top, torch.full_like(rank, 100), torch.full_like(rank, 300 + 20 * li))
         add_edges(src, nb.reshape(-1), base + rank)
         if li >= 1 and li + 1 < len(levels):  # parent -> child edges
-            parents = levels[li + 1]
-            par = _nearest_parent(x, ids, parents)
-            sim = (x[ids] * x[parents[par]]).sum(1)
-            o = torch.argsort(par * 4.0 - sim.double())  # by parent, most similar child first
-            par_s, child_s = par[o], ids[o]
+            # children: nodes whose top level is li; parents: nodes whose top level is li + 1
+            # (all nodes of the last level).  A node thus lists children of one level only.
+            last = li + 1 == len(levels) - 1
+            pl = levels[li + 1]
+            parents = pl if last else pl[top_level_of[pl] == li + 1]
+            ids_c = ids[top_level_of[ids] == li]
+            if parents.numel() == 0 or ids_c.numel() == 0:
+                continue
+            ids_saved, ids = ids, ids_c
+            par2 = _nearest_parent(x, ids, parents)
+            par = par2.reshape(-1)
+            chd = ids[:, None].expand_as(par2).reshape(-1)
+            sim = (x[chd] * x[parents[par]]).sum(1)
+            o = torch.argsort(par.double() * 4.0 - sim.double())  # by parent, most similar child first
+            par_s, child_s = par[o], chd[o]
             first = torch.ones_like(par_s, dtype=torch.bool)
             first[1:] = par_s[1:] != par_s[:-1]
             seg_start = torch.nonzero(first).squeeze(1)
             seg_id = torch.cumsum(first.to(torch.int64), 0) - 1
             within = torch.arange(par_s.numel(), device=dev) - seg_start[seg_id]
-            okc = within < child_cap
-            add_edges(parents[par_s][okc], child_s[okc], within[okc])
+            # candidate children per parent (nearest first), then the same diversified choice
+            # as for neighbours: one child per direction, so that a parent lists children of
+            # every cluster it is responsible for, not 30 siblings of its own cluster
+            cpool = 6 * child_cap
+            okc = within < cpool
+            cand = torch.full((parents.numel(), cpool), -1, dtype=torch.int64, device=dev)
+            cand[par_s[okc], within[okc]] = child_s[okc]
+            ch = _diversify(x, parents, cand, child_cap)
+            psrc = parents[:, None].expand_as(ch).reshape(-1)
+            prank = torch.arange(ch.shape[1], device=dev)[None, :].expand_as(ch).reshape(-1)
+            add_edges(psrc, ch.reshape(-1), prank)
+            ids = ids_saved
     src, dst, prio = torch.cat(E_src), torch.cat(E_dst), torch.cat(E_prio)
     # reverse edges rank behind every forward edge
     src, dst, prio = torch.cat([src, dst]), torch.cat([dst, src]), torch.cat([prio, prio + 1000])
