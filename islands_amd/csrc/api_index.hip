@@ -2,7 +2,7 @@
 // bincode (de)serialisation, device upload of the CSR graph and of the
 // in-memory embedding provider.  Mirrors src/core/leann.rs of the reference;
 // each function cites the lines it replaces.
-#include "common.hpp"
+#include "device_common.cuh"
 
 #include <algorithm>
 #include <cmath>
@@ -240,6 +240,7 @@ void isl_index_free(isl_index* idx) {
     if (idx->d_off) (void)hipFree(idx->d_off);
     if (idx->d_adj) (void)hipFree(idx->d_adj);
     if (idx->d_emb) (void)hipFree(idx->d_emb);
+    if (idx->d_norm2) (void)hipFree(idx->d_norm2);
     free_workspace(idx->ws);
   }
   delete idx;
@@ -424,6 +425,22 @@ __global__ void convert_adj_kernel(const uint64_t* __restrict__ in, uint32_t* __
     out[i] = (uint32_t)v;
   }
   if (bad) atomicOr(flags, 1u);
+}
+
+// norm2[i] = sum_j rows[i][j]^2, sequential in j (one lane per row, rows staged through LDS).
+__global__ __launch_bounds__(64) void row_norm2_kernel(const float* __restrict__ rows, uint64_t n,
+                                                       uint32_t d, uint64_t stride,
+                                                       float* __restrict__ norm2) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* tile = reinterpret_cast<float*>(smem);
+  const int lane = threadIdx.x;
+  for (uint64_t base = (uint64_t)blockIdx.x * 64; base < n; base += (uint64_t)gridDim.x * 64) {
+    uint32_t R = (uint32_t)(n - base < 64 ? n - base : 64);
+    // the query operand is ignored by SUMSQ_RAW; `tile` only serves as a valid LDS address
+    float v = isl_dev::wave_distances<isl_dev::METRIC_SUMSQ_RAW>(rows + base * stride, stride, d,
+                                                                  (uint32_t)lane, R, tile, tile, 0.f);
+    if ((uint32_t)lane < R) norm2[base + lane] = v;
+  }
 }
 
 // One thread per row: max degree, duplicate ids within a row (flag bit 1).
@@ -641,6 +658,19 @@ isl_status isl_set_embeddings(isl_index* idx, const void* rows, uint64_t n, uint
   idx->nvec = n;
   idx->emb_d = d;
   idx->emb_stride = stride;
+  // norm_b of cosine_distance (distance.rs:79) depends on the row alone: computed once, in the
+  // reference's left-to-right order, and reused by every search
+  if (idx->d_norm2) { (void)hipFree(idx->d_norm2); idx->d_norm2 = nullptr; }
+  ISL_HIP(hipMalloc(&idx->d_norm2, (size_t)n * 4));
+  {
+    using namespace isl_dev;
+    size_t lds = (size_t)TILE_ROWS * TILE_LD * 4 + 64;
+    uint32_t grid = (uint32_t)std::min<uint64_t>((n + 63) / 64, 8192);
+    hipLaunchKernelGGL(row_norm2_kernel, dim3(grid), dim3(64), lds, 0, idx->d_emb, n, (uint32_t)d,
+                       stride, idx->d_norm2);
+    ISL_HIP(hipGetLastError());
+    ISL_HIP(hipDeviceSynchronize());
+  }
   return ISL_OK;
 }
 

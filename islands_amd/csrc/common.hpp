@@ -103,6 +103,7 @@ struct isl_index {
   uint32_t max_degree = 0;
   // in-memory provider (leann.rs:104-159): nvec rows, `stride` floats apart
   float* d_emb = nullptr;
+  float* d_norm2 = nullptr;  // [nvec] sum of squares of every row, reference summation order
   uint64_t nvec = 0, emb_d = 0, emb_stride = 0;
 
   mutable std::mutex mu;  // serialises searches that share the workspace

@@ -8,11 +8,15 @@
 
 namespace isl_dev {
 
-constexpr int SLAB = 64;            // floats of each row staged per step (256 B)
-constexpr int TILE_LD = SLAB + 4;   // LDS row pitch in floats: 68*r mod 64 = 4r -> conflict-free b128
-constexpr int TILE_ROWS = 64;
+constexpr int PIECE = 256;           // floats of one row moved by one wave-instruction (1 KiB)
+constexpr int TILE_LD = PIECE + 4;   // LDS row pitch in floats: 260*r mod 64 = 4r -> conflict-free b128
+constexpr int GROUP = 16;            // rows staged together
+constexpr int TILE_ROWS = GROUP;
 constexpr int METRIC_SUMSQ = 100;   // internal: sqrt(sum x*x) (normalize_vector, distance.rs:126)
 constexpr int METRIC_EUCLID_SQ = 101;  // internal: sum (q-x)^2 without sqrt (pq.rs:295-299)
+constexpr int METRIC_SUMSQ_RAW = 102;  // internal: sum x*x (norm_b of distance.rs:79, precomputed per row)
+constexpr int METRIC_COSINE_PRE = 103; // internal: cosine with norm_b supplied per row (same value as
+                                       // the on-the-fly chain: it is a sum over the row alone)
 
 // ---------------------------------------------------------------- wave helpers
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
@@ -69,7 +73,9 @@ __device__ __forceinline__ void dstep(float q, float x, float& a0, float& a1) {
     a0 += diff * diff;
   } else if (METRIC == ISL_METRIC_DOT) {
     a0 += q * x;
-  } else if (METRIC == METRIC_SUMSQ) {
+  } else if (METRIC == METRIC_COSINE_PRE) {
+    a0 += q * x;  // dot += x*y; norm_b comes precomputed
+  } else if (METRIC == METRIC_SUMSQ || METRIC == METRIC_SUMSQ_RAW) {
     a0 += x * x;
   } else if (METRIC == METRIC_EUCLID_SQ) {
     float diff = q - x;
@@ -81,7 +87,7 @@ __device__ __forceinline__ void dstep(float q, float x, float& a0, float& a1) {
 
 template <int METRIC>
 __device__ __forceinline__ float dfinish(float a0, float a1, float q_norm) {
-  if (METRIC == ISL_METRIC_COSINE) {
+  if (METRIC == ISL_METRIC_COSINE || METRIC == METRIC_COSINE_PRE) {
     float norm = sqrtf(q_norm * a1);  // (norm_a * norm_b).sqrt(), distance.rs:82
     if (norm == 0.0f) return 1.0f;
     return 1.0f - (a0 / norm);
@@ -95,82 +101,139 @@ __device__ __forceinline__ float dfinish(float a0, float a1, float q_norm) {
   return a0;  // Manhattan, squared Euclidean
 }
 
-// Distances of R (<= 64) rows to the query held in LDS; lane r < R owns row `rid`
-// and returns its distance.  tile: TILE_ROWS x TILE_LD floats of LDS.
+// Distances of R (<= 64) rows to the query held in LDS (`qs`); lane r < R owns row `rid` and returns
+// its distance.  Rows are handled in groups of GROUP: every wave-instruction moves one whole
+// 1-KiB piece (PIECE floats) of ONE row, fully coalesced; two pieces per row are in flight
+// (register double buffer A/B) while lanes 0..GROUP-1 run the sequential chains of the piece
+// that already sits in the LDS tile (GROUP x TILE_LD floats, conflict-free ds_read_b128).
 template <int METRIC>
-__device__ __forceinline__ float wave_distances(const float* __restrict__ emb, uint64_t stride, uint32_t d,
-                                uint32_t rid, uint32_t R, const float* qs, float* tile,
-                                float q_norm) {
+__device__ __forceinline__ float wave_distances(const float* __restrict__ emb, uint64_t stride,
+                                                uint32_t d, uint32_t rid, uint32_t R,
+                                                const float* qs, float* tile, float q_norm,
+                                                float row_aux = 0.0f, uint64_t* prof3 = nullptr) {
   const int lane = threadIdx.x;
-  const int sub = lane & 15;   // which float4 of the 64-float slab this lane moves
-  const int rgrp = lane >> 4;  // which of the 4 rows of a piece
-  const uint32_t npieces = (R + 3) >> 2;
-  const uint32_t nslab = (d + SLAB - 1) / SLAB;
-  // 16 named pieces (hipcc keeps a float4[16] indexed from unrolled loops in scratch)
+  const uint32_t nT = (d + PIECE - 1) / PIECE;
+  float result = 0.0f;
 #define ISL_FOR16(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
-#define ISL_DECL(p)                                                        \
-  float4 r##p = make_float4(0.f, 0.f, 0.f, 0.f);                           \
-  const bool on##p = (uint32_t)(p) < npieces && (uint32_t)(4 * (p) + rgrp) < R; \
-  const float* rp##p = emb + (uint64_t)__shfl(rid, (4 * (p) + rgrp) & 63) * stride + sub * 4;
-  ISL_FOR16(ISL_DECL)
-// piece p = rows 4p..4p+3, 256 B each: one fully coalesced wave-instruction
-#define ISL_LOAD(p) if (on##p) r##p = *reinterpret_cast<const float4*>(rp##p + soff);
-#define ISL_STORE(p) \
-  if (on##p) *reinterpret_cast<float4*>(tile + (4 * (p) + rgrp) * TILE_LD + sub * 4) = r##p;
-  float a0 = 0.0f, a1 = 0.0f;
-  {
-    const size_t soff = 0;
-    ISL_FOR16(ISL_LOAD)
-  }
-  for (uint32_t s = 0; s < nslab; ++s) {
-    ISL_FOR16(ISL_STORE)
-    __syncthreads();
-    if (s + 1 < nslab) {  // in flight while this slab is consumed
-      const size_t soff = (size_t)(s + 1) * SLAB;
-      ISL_FOR16(ISL_LOAD)
-    }
-    if ((uint32_t)lane < R) {
-      const float* trow = tile + lane * TILE_LD;
-      const float* qv = qs + s * SLAB;
-      uint32_t cnt = d - s * SLAB;
-      if (cnt >= (uint32_t)SLAB) {
-#pragma unroll
-        for (int j = 0; j < SLAB; j += 4) {
-          float4 x = *reinterpret_cast<const float4*>(trow + j);
-          float4 q = *reinterpret_cast<const float4*>(qv + j);
-          dstep<METRIC>(q.x, x.x, a0, a1);
-          dstep<METRIC>(q.y, x.y, a0, a1);
-          dstep<METRIC>(q.z, x.z, a0, a1);
-          dstep<METRIC>(q.w, x.w, a0, a1);
+  for (uint32_t g0 = 0; g0 < R; g0 += GROUP) {
+    const uint32_t Rg = R - g0 < (uint32_t)GROUP ? R - g0 : (uint32_t)GROUP;
+    // wave-uniform row bases (scalar registers) + this lane's 16-byte column
+#define ISL_DECL(j)                                                                        \
+  const bool on##j = (uint32_t)(j) < Rg;                                                   \
+  const float* rp##j = emb + (uint64_t)rl_u(rid, (int)((g0 + (j)) & 63)) * stride + lane * 4; \
+  float4 ra##j = make_float4(0.f, 0.f, 0.f, 0.f), rb##j = make_float4(0.f, 0.f, 0.f, 0.f),  \
+         rc##j = make_float4(0.f, 0.f, 0.f, 0.f);
+    ISL_FOR16(ISL_DECL)
+#define ISL_LOAD_A(j) if (on##j) ra##j = *reinterpret_cast<const float4*>(rp##j + poff);
+#define ISL_LOAD_B(j) if (on##j) rb##j = *reinterpret_cast<const float4*>(rp##j + poff);
+#define ISL_LOAD_C(j) if (on##j) rc##j = *reinterpret_cast<const float4*>(rp##j + poff);
+#define ISL_STORE_A(j) if (on##j) *reinterpret_cast<float4*>(tile + (j) * TILE_LD + lane * 4) = ra##j;
+#define ISL_STORE_B(j) if (on##j) *reinterpret_cast<float4*>(tile + (j) * TILE_LD + lane * 4) = rb##j;
+#define ISL_STORE_C(j) if (on##j) *reinterpret_cast<float4*>(tile + (j) * TILE_LD + lane * 4) = rc##j;
+    float a0 = 0.0f, a1 = 0.0f;
+    auto consume = [&](uint32_t t) {
+      uint64_t tl0 = (prof3 && t == 2) ? __builtin_amdgcn_s_memtime() : 0;
+      if ((uint32_t)lane < Rg) {
+        const float* trow = tile + lane * TILE_LD;
+        // unroll 8 keeps 16 ds_read_b128 in flight: measured sweet spot for one wave per SIMD
+        // (16.2 cycles/element; unroll 16 -> 26.5, unroll 4 -> 18.9; q through the scalar cache
+        // is faster only while the query stays in that cache, which it does not here)
+        const float* qv = qs + t * PIECE;
+        const uint32_t cnt = d - t * PIECE;
+        if (cnt >= (uint32_t)PIECE) {
+#pragma unroll 8
+          for (int j = 0; j < PIECE; j += 4) {
+            float4 x = *reinterpret_cast<const float4*>(trow + j);
+            float4 q = *reinterpret_cast<const float4*>(qv + j);
+            dstep<METRIC>(q.x, x.x, a0, a1);
+            dstep<METRIC>(q.y, x.y, a0, a1);
+            dstep<METRIC>(q.z, x.z, a0, a1);
+            dstep<METRIC>(q.w, x.w, a0, a1);
+          }
+        } else {
+          for (uint32_t j = 0; j < cnt; ++j) dstep<METRIC>(qv[j], trow[j], a0, a1);
         }
-      } else {
-        for (uint32_t j = 0; j < cnt; ++j) dstep<METRIC>(qv[j], trow[j], a0, a1);
+      }
+      if (prof3 && t == 2) prof3[2] += __builtin_amdgcn_s_memtime() - tl0;
+    };
+    // three pieces per row in flight: a whole 768-float row is requested at once
+    uint64_t tw0 = prof3 ? __builtin_amdgcn_s_memrealtime() : 0;
+    {
+      const size_t poff = 0;
+      ISL_FOR16(ISL_LOAD_A)
+    }
+    if (nT > 1) {
+      const size_t poff = PIECE;
+      ISL_FOR16(ISL_LOAD_B)
+    }
+    if (nT > 2) {
+      const size_t poff = 2 * PIECE;
+      ISL_FOR16(ISL_LOAD_C)
+    }
+    for (uint32_t t = 0; t < nT; t += 3) {
+      ISL_FOR16(ISL_STORE_A)
+      __syncthreads();
+      uint64_t tc0 = 0;
+      if (prof3 && t == 0) { uint64_t n_ = __builtin_amdgcn_s_memrealtime(); prof3[0] += n_ - tw0; tw0 = n_; tc0 = __builtin_amdgcn_s_memtime(); }
+      if (t + 3 < nT) {
+        const size_t poff = (size_t)(t + 3) * PIECE;
+        ISL_FOR16(ISL_LOAD_A)
+      }
+      consume(t);
+      __syncthreads();
+      if (prof3 && t == 0) { uint64_t n_ = __builtin_amdgcn_s_memrealtime(); prof3[1] += n_ - tw0; tw0 = n_; (void)tc0; }
+      if (t + 1 < nT) {
+        ISL_FOR16(ISL_STORE_B)
+        __syncthreads();
+        if (t + 4 < nT) {
+          const size_t poff = (size_t)(t + 4) * PIECE;
+          ISL_FOR16(ISL_LOAD_B)
+        }
+        consume(t + 1);
+        __syncthreads();
+      }
+      if (t + 2 < nT) {
+        ISL_FOR16(ISL_STORE_C)
+        __syncthreads();
+        if (t + 5 < nT) {
+          const size_t poff = (size_t)(t + 5) * PIECE;
+          ISL_FOR16(ISL_LOAD_C)
+        }
+        consume(t + 2);
+        __syncthreads();
       }
     }
-    __syncthreads();
+    if (METRIC == METRIC_COSINE_PRE) a1 = __shfl(row_aux, (int)((g0 + lane) & 63));
+    float dist = dfinish<METRIC>(a0, a1, q_norm);
+    // lane j of this group computed row g0 + j: hand the value to lane g0 + j
+    float moved = __shfl(dist, (lane - (int)g0) & 63);
+    if ((uint32_t)lane >= g0 && (uint32_t)lane < g0 + Rg) result = moved;
+#undef ISL_DECL
+#undef ISL_LOAD_A
+#undef ISL_LOAD_B
+#undef ISL_STORE_A
+#undef ISL_STORE_B
+#undef ISL_LOAD_C
+#undef ISL_STORE_C
   }
 #undef ISL_FOR16
-#undef ISL_DECL
-#undef ISL_LOAD
-#undef ISL_STORE
-  return dfinish<METRIC>(a0, a1, q_norm);
+  return result;
 }
 
-// Loads query `qi` into LDS and returns norm_a (cosine) computed in reference order.
+// Copies the query at `q` (global) into LDS and returns norm_a of cosine_distance
+// (distance.rs:78) computed in reference order.
 template <int METRIC>
-__device__ __forceinline__ float load_query(const float* __restrict__ queries, uint32_t qi, uint32_t d, float* qs) {
-  const float* q = queries + (uint64_t)qi * d;
+__device__ __forceinline__ float load_query(const float* __restrict__ q, uint32_t d, float* qs) {
   for (uint32_t j = threadIdx.x; j < d; j += 64) qs[j] = q[j];
   __syncthreads();
   float na = 0.0f;
-  if (METRIC == ISL_METRIC_COSINE) {
+  if (METRIC == ISL_METRIC_COSINE || METRIC == METRIC_COSINE_PRE) {
     for (uint32_t j = 0; j < d; ++j) {
       float x = qs[j];
-      na += x * x;  // norm_a += x*x, distance.rs:78
+      na += x * x;
     }
   }
   return na;
 }
-
 
 }  // namespace isl_dev

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(64) void distance_batch_kernel(const float* __restr
   float* tile = reinterpret_cast<float*>(smem);
   float* qs = tile + TILE_ROWS * TILE_LD;
   const int lane = threadIdx.x;
-  const float q_norm = load_query<METRIC>(query, 0, d, qs);
+  const float q_norm = load_query<METRIC>(query, d, qs);
   for (uint64_t base = (uint64_t)blockIdx.x * 64; base < n; base += (uint64_t)gridDim.x * 64) {
     uint32_t R = (uint32_t)(n - base < 64 ? n - base : 64);
     // row ids relative to `base` keep the 32-bit id type of wave_distances
@@ -67,7 +67,7 @@ void launch_dist(uint32_t grid, hipStream_t st, const float* q, const float* row
   hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, q, rows, n, d, stride, out);
 }
 
-// rows must be readable SLAB floats past the last row end -> stage into a padded buffer
+// rows must be readable one PIECE past the last row end -> stage into a padded buffer
 isl_status run_distance(int32_t metric, const float* query, uint64_t d, const float* rows,
                         uint64_t n, float* out, int32_t mem, int32_t device, hipStream_t st) {
   ISL_TRY(isl::use_device(device));

@@ -31,9 +31,7 @@ __global__ __launch_bounds__(64) void pq_tables_kernel(const float* __restrict__
   const uint32_t cblocks = (K + 63) / 64;
   const uint32_t q = blockIdx.y;
   const uint32_t j = blockIdx.x / cblocks, c0 = (blockIdx.x % cblocks) * 64;
-  const float* qsub = queries + (uint64_t)q * d + (uint64_t)j * dsub;
-  for (uint32_t i = lane; i < dsub; i += 64) qs[i] = qsub[i];
-  __syncthreads();
+  (void)load_query<METRIC_EUCLID_SQ>(queries + (uint64_t)q * d + (uint64_t)j * dsub, dsub, qs);
   uint32_t R = K - c0 < 64 ? K - c0 : 64;
   const float* rows = cb + ((uint64_t)j * K + c0) * cstride;
   float v = wave_distances<METRIC_EUCLID_SQ>(rows, cstride, dsub, (uint32_t)lane, R, qs, tile, 0.f);
@@ -72,7 +70,7 @@ __global__ __launch_bounds__(64) void pq_encode_kernel(const float* __restrict__
   const int lane = threadIdx.x;
   const uint32_t j = blockIdx.x;
   const uint64_t v = blockIdx.y;
-  const float q_norm = load_query<METRIC>(vectors + v * d + (uint64_t)j * dsub, 0, dsub, qs);
+  const float q_norm = load_query<METRIC>(vectors + v * d + (uint64_t)j * dsub, dsub, qs);
   float best = FLT_MAX;
   uint32_t best_idx = 0;
   bool have = false;

@@ -26,6 +26,7 @@
 #include "device_common.cuh"
 
 #include <algorithm>
+#include <map>
 
 namespace {
 
@@ -49,6 +50,7 @@ struct SearchParams {
   const uint32_t* adj;
   uint64_t num_nodes;
   const float* emb;
+  const float* norm2;  // per-row sum of squares (cosine only), reference order
   uint64_t nvec;
   uint64_t stride;  // floats between rows
   uint32_t d;
@@ -68,6 +70,7 @@ struct SearchParams {
                      // [4] replay head, [8..11] why the fast kernel gave a query up
   uint32_t* redo;    // [nq] queries for the exact kernel
   uint32_t* replay;  // [nq] queries for the replay kernel
+  uint64_t* prof;    // optional [nq][8] phase timers (100 MHz ticks), ISL_DEBUG only
   uint2* plog;       // [nq][plog_cap] (distance bits, id) of every results.push, in order
   uint32_t plog_cap;
   uint32_t hbits;    // LDS visited table: 1 << hbits entries
@@ -157,251 +160,6 @@ struct RSet {
   }
 };
 
-// ------------------------------------------------------------------ fast kernel
-template <int S, int METRIC>
-__global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = threadIdx.x;
-  const uint32_t hcap = 1u << p.hbits;
-  const uint32_t hmask = hcap - 1;
-  const uint32_t hlimit = hcap - hcap / 4;  // load factor 0.75
-  uint32_t* htab = reinterpret_cast<uint32_t*>(smem);
-  float* tile = reinterpret_cast<float*>(smem + (size_t)hcap * 4);
-  uint32_t* scratch = reinterpret_cast<uint32_t*>(tile + TILE_ROWS * TILE_LD);
-  float* qs = reinterpret_cast<float*>(scratch + 64);
-  const uint32_t ocap = 1u << p.obits;
-  const uint32_t omask = ocap - 1;
-  const uint32_t olimit = ocap - ocap / 4;
-  uint32_t* otab = p.otab + (size_t)blockIdx.x * ocap;
-  const uint32_t ef = p.ef;
-
-  for (;;) {
-    uint32_t qi = 0;
-    if (lane == 0) qi = atomicAdd(&p.ticket[0], 1u);
-    qi = uni(qi);
-    if (qi >= p.nq) break;
-
-    for (uint32_t i = lane; i < hcap; i += 64) htab[i] = EMPTY;
-    const float q_norm = load_query<METRIC>(p.queries, qi, p.d, qs);  // syncs
-
-    RSet<S> rs;
-    rs.init();
-    uint32_t hcount = 0, ocount = 0;
-    bool ovf = false;
-    uint32_t status = QS_OK;
-    uint64_t payload = 0;
-    uint32_t cH = 0, cE = 0, cV = 0, cP = 0;
-    // Tie-evicted candidates (DESIGN.md section 3.3): entries pushed out of R whose distance
-    // equals the new worst distance stay poppable in the reference's candidate heap.  Lane i <
-    // tcount holds one id; they all share the current worst distance and die when it drops.
-    uint32_t t_id = 0, tcount = 0;
-    uint2* plog = p.plog + (size_t)qi * p.plog_cap;
-
-    // entry point: provider.compute_embedding(entry) + distance, leann.rs:911-916
-    if ((uint64_t)p.entry >= p.nvec) {
-      status = QS_NODE_NOT_FOUND;
-      payload = p.entry;
-    } else {
-      float ed = wave_distances<METRIC>(p.emb, p.stride, p.d, p.entry, 1, qs, tile, q_norm);
-      ed = rl_f(ed, 0);
-      cV = 1;
-      if (lane == 0) htab[hslot(p.entry, p.hbits)] = p.entry;
-      hcount = 1;
-      rs.insert(ed, p.entry);
-      if (lane == 0) plog[0] = make_uint2(__float_as_uint(ed), p.entry);
-      cP = 1;
-      __syncthreads();
-    }
-
-    while (status == QS_OK) {
-      // candidates.pop(): the smallest unexpanded key of R (leann.rs:922); when none is
-      // left every remaining candidate is farther than the worst result -> break (:924-928)
-      uint32_t e = rs.first_unexpanded();
-      uint32_t cid;
-      if (e != 0xFFFFFFFFu) {
-        cid = rs.id_at(e) & ID_MASK;
-        rs.mark_expanded(e);
-      } else if (tcount > 0) {
-        // every key of R is expanded; the next candidates are the tie-evicted ones, whose
-        // distance equals the worst result (`dist > worst` is false, leann.rs:925): smallest id first
-        uint32_t best = rl_u(t_id, 0);
-        int bl = 0;
-        for (uint32_t i = 1; i < tcount; ++i) {
-          uint32_t v = rl_u(t_id, (int)i);
-          if (v < best) { best = v; bl = (int)i; }
-        }
-        uint32_t last = rl_u(t_id, (int)(tcount - 1));
-        if (lane == bl) t_id = last;
-        tcount -= 1;
-        cid = best;
-      } else {
-        break;
-      }
-      if ((uint64_t)cid >= p.num_nodes) continue;  // get_neighbors -> None, leann.rs:227-229
-      uint64_t o0 = p.off[cid], o1 = p.off[cid + 1];
-      uint32_t deg = (uint32_t)(o1 - o0);
-      cH += 1;
-      cE += deg;
-      if (deg == 0) continue;
-      if (deg > 64) { status = QS_REDO; payload = 1; break; }  // long rows: exact kernel
-      bool active = (uint32_t)lane < deg;
-      uint32_t nid = active ? p.adj[o0 + lane] : EMPTY;
-
-      // visited.insert(n), leann.rs:933-937 (rows hold no duplicate ids on the device)
-      if (!ovf && hcount + deg > hlimit) ovf = true;
-      bool is_new = false;
-      if (active) {
-        uint32_t h = hslot(nid, p.hbits);
-        if (!ovf) {
-          for (;;) {
-            uint32_t old = atomicCAS(&htab[h], EMPTY, nid);
-            if (old == EMPTY) { is_new = true; break; }
-            if (old == nid) break;
-            h = (h + 1) & hmask;
-          }
-        } else {
-          bool found = false;
-          for (;;) {
-            uint32_t cur = htab[h];
-            if (cur == nid) { found = true; break; }
-            if (cur == EMPTY) break;
-            h = (h + 1) & hmask;
-          }
-          if (!found) {
-            uint32_t g = hslot(nid, p.obits);
-            for (;;) {
-              uint32_t old = atomicCAS(&otab[g], EMPTY, nid);
-              if (old == EMPTY) { is_new = true; break; }
-              if (old == nid) break;
-              g = (g + 1) & omask;
-            }
-          }
-        }
-      }
-      uint64_t nm = ballot(is_new);
-      uint32_t nu = (uint32_t)__popcll(nm);
-      if (!ovf) hcount += nu;
-      else {
-        ocount += nu;
-        if (ocount > olimit) { status = QS_REDO; payload = 2; break; }
-      }
-      if (nu == 0) continue;  // leann.rs:939-941
-
-      // compact the unvisited ids, CSR order preserved
-      uint32_t rank = (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
-      if (is_new) scratch[rank] = nid;
-      __syncthreads();
-      uint32_t uid = (uint32_t)lane < nu ? scratch[lane] : 0u;
-      __syncthreads();
-
-      uint32_t keep = prune_keep(p.prune_ratio, p.prune_strategy, nu, rs.len, ef);  // :944
-      // compute_embeddings_batch, leann.rs:947: the first missing id fails the query
-      uint64_t bad = ballot((uint32_t)lane < keep && (uint64_t)uid >= p.nvec);
-      if (bad) {
-        int bl = __ffsll((long long)bad) - 1;
-        status = QS_NODE_NOT_FOUND;
-        payload = rl_u(uid, bl);
-        break;
-      }
-      cV += keep;
-      float nd = wave_distances<METRIC>(p.emb, p.stride, p.d, uid, keep, qs, tile, q_norm);
-
-      // leann.rs:953-970 in CSR order; worst = results.peek()
-      uint64_t pending = keep >= 64 ? ~0ull : ((1ull << keep) - 1ull);
-      while (pending) {
-        bool full = rs.len >= ef;
-        float worst = rs.len ? rs.dist_at(rs.len - 1) : 0.0f;
-        bool pass = !full || rs.len == 0 || nd < worst;  // raw f32 `<`, leann.rs:959
-        uint64_t pm = ballot(pass) & pending;
-        if (!pm) break;
-        int r = __ffsll((long long)pm) - 1;
-        float id_d = rl_f(nd, r);
-        uint32_t id_i = rl_u(uid, r);
-        if (cP < p.plog_cap) {
-          if (lane == 0) plog[cP] = make_uint2(__float_as_uint(id_d), id_i);
-        }
-        if (full) {
-          // results.push + pop: the old worst leaves R but stays in the reference's candidate
-          // heap.  It can only be popped again while its distance still equals the worst one.
-          float old_worst = worst;
-          uint32_t old_raw = rs.id_at(ef - 1);
-          rs.insert(id_d, id_i);
-          rs.len = ef;
-          float new_worst = rs.dist_at(ef - 1);
-          if (ordkey(old_worst) != ordkey(new_worst)) {
-            tcount = 0;
-          } else if (!(old_raw & FLAG_EXP)) {
-            if (tcount >= 64) { status = QS_REDO; payload = 3; }
-            else {
-              if (lane == (int)tcount) t_id = old_raw & ID_MASK;
-              tcount += 1;
-            }
-          }
-        } else {
-          rs.insert(id_d, id_i);
-        }
-        cP += 1;
-        pending &= ~((2ull << r) - 1ull);
-        if (r == 63) pending = 0;
-      }
-    }
-
-    // results sorted by distance, take(k): leann.rs:984-986, :895
-    uint32_t outn = rs.len < p.k ? rs.len : p.k;
-    if (status == QS_OK) {
-      // equal distances inside the returned prefix (or across its boundary) are ordered by
-      // BinaryHeap array order in the reference: let the exact kernel reproduce that
-      uint32_t chk = rs.len < p.k + 1 ? rs.len : p.k + 1;
-      bool tie = false;
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        uint32_t e = s * 64 + lane;
-        float nxt = __shfl_down(rs.d[s], 1);
-        if (s + 1 < S) {
-          float nd0 = rl_f(rs.d[s + 1 < S ? s + 1 : s], 0);
-          if (lane == 63) nxt = nd0;
-        }
-        if (e + 1 < chk && ordkey(rs.d[s]) == ordkey(nxt)) tie = true;
-      }
-      if (ballot(tie)) {
-        if (cP <= p.plog_cap) status = QS_REPLAY;
-        else { status = QS_REDO; payload = 4; }
-      }
-    }
-    if (status == QS_OK) {
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        uint32_t e = s * 64 + lane;
-        if (e < outn) {
-          p.out_ids[(uint64_t)qi * p.k + e] = (uint64_t)(rs.id[s] & ID_MASK);
-          p.out_dist[(uint64_t)qi * p.k + e] = rs.d[s];
-        }
-      }
-    }
-    if (lane == 0) {
-      p.status[qi] = status;
-      p.payload[qi] = payload;
-      p.out_count[qi] = status == QS_OK ? outn : 0u;
-      p.ctr[qi * 4 + 0] = cH;
-      p.ctr[qi * 4 + 1] = cE;
-      p.ctr[qi * 4 + 2] = cV;
-      p.ctr[qi * 4 + 3] = cP;
-      if (status == QS_REDO) {
-        p.redo[atomicAdd(&p.ticket[1], 1u)] = qi;
-        // why: 1 long row, 2 visited overflow, 3 tie-candidate overflow, 0 push-log overflow
-        atomicAdd(&p.ticket[8 + ((uint32_t)payload & 3u)], 1u);
-      } else if (status == QS_REPLAY) {
-        p.replay[atomicAdd(&p.ticket[3], 1u)] = qi;
-      }
-    }
-    if (ovf) {  // leave the overflow table empty for the next query of this slot
-      for (uint32_t i = lane; i < ocap; i += 64) otab[i] = EMPTY;
-    }
-    __syncthreads();
-  }
-}
-
-// ----------------------------------------------------------------- exact kernel
 // Rust BinaryHeap ([external]: std): max-heap w.r.t. `less_eq`.  Operated by lane 0 only.
 struct ResultOrder {  // (OrderedFloat<f32>, u64), leann.rs:908
   __device__ static bool le(float ad, uint32_t ai, float bd, uint32_t bi) {
@@ -471,8 +229,339 @@ __device__ void heap_pop(float* hd, uint32_t* hi, uint64_t& len, float& od, uint
   oi = iti;
 }
 
-template <int METRIC>
+// Re-emits the first k results in the reference's order when equal distances make Rust's
+// BinaryHeap array layout observable (results.into_iter() + stable sort, leann.rs:984-986):
+// replays the logged sequence of results.push (and the pop that follows each push beyond ef)
+// on an exact BinaryHeap emulation in LDS.  The result SET of the fast kernel is already exact.
+__device__ void replay_result_order(const uint2* plog, uint32_t npush, uint32_t ef, uint32_t k,
+                                    uint32_t qi, float* res_d, uint32_t* res_i, uint2* stage,
+                                    uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
+  const int lane = threadIdx.x;
+  uint64_t rlen = 0;
+  for (uint32_t base = 0; base < npush; base += 64) {
+    if (base + lane < npush) stage[lane] = plog[base + lane];
+    __syncthreads();
+    if (lane == 0) {
+      uint32_t cnt = npush - base < 64 ? npush - base : 64;
+      for (uint32_t i = 0; i < cnt; ++i) {
+        heap_push<ResultOrder>(res_d, res_i, rlen, __uint_as_float(stage[i].x), stage[i].y);
+        if (rlen > ef) {
+          float dd;
+          uint32_t di;
+          heap_pop<ResultOrder>(res_d, res_i, rlen, dd, di);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    // only the first k entries of the stable sort are needed: k rounds of "first minimum"
+    uint32_t outn = rlen < k ? (uint32_t)rlen : k;
+    for (uint32_t o = 0; o < outn; ++o) {
+      uint64_t best = o;
+      for (uint64_t i = o + 1; i < rlen; ++i)
+        if (res_d[i] < res_d[best]) best = i;  // strict: the earliest of equal distances wins
+      float bd = res_d[best];
+      uint32_t bi = res_i[best];
+      for (uint64_t i = best; i > o; --i) {  // keep the relative order of the others (stable)
+        res_d[i] = res_d[i - 1];
+        res_i[i] = res_i[i - 1];
+      }
+      res_d[o] = bd;
+      res_i[o] = bi;
+      out_ids[(uint64_t)qi * k + o] = (uint64_t)bi;
+      out_dist[(uint64_t)qi * k + o] = bd;
+    }
+    out_count[qi] = outn;
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------ fast kernel
+template <int S, int METRIC_API>
+__global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
+  constexpr int METRIC = METRIC_API == ISL_METRIC_COSINE ? METRIC_COSINE_PRE : METRIC_API;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const uint32_t hcap = 1u << p.hbits;
+  const uint32_t hmask = hcap - 1;
+  const uint32_t hlimit = hcap - hcap / 4;  // load factor 0.75
+  uint32_t* htab = reinterpret_cast<uint32_t*>(smem);
+  float* tile = reinterpret_cast<float*>(smem + (size_t)hcap * 4);
+  uint32_t* scratch = reinterpret_cast<uint32_t*>(tile + TILE_ROWS * TILE_LD);
+  float* qs = reinterpret_cast<float*>(scratch + 64);
+  const uint32_t ocap = 1u << p.obits;
+  const uint32_t omask = ocap - 1;
+  const uint32_t olimit = ocap - ocap / 4;
+  uint32_t* otab = p.otab + (size_t)blockIdx.x * ocap;
+  const uint32_t ef = p.ef;
+
+  for (;;) {
+    uint32_t qi = 0;
+    if (lane == 0) qi = atomicAdd(&p.ticket[0], 1u);
+    qi = uni(qi);
+    if (qi >= p.nq) break;
+
+    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+    for (uint32_t i = lane; i < hcap; i += 64) htab[i] = EMPTY;
+    const float q_norm = load_query<METRIC>(p.queries + (uint64_t)qi * p.d, p.d, qs);  // syncs
+
+    RSet<S> rs;
+    rs.init();
+    uint32_t hcount = 0, ocount = 0;
+    bool ovf = false;
+    uint32_t status = QS_OK;
+    uint64_t payload = 0;
+    uint32_t cH = 0, cE = 0, cV = 0, cP = 0;
+    // Tie-evicted candidates (DESIGN.md section 3.3): entries pushed out of R whose distance
+    // equals the new worst distance stay poppable in the reference's candidate heap.  Lane i <
+    // tcount holds one id; they all share the current worst distance and die when it drops.
+    uint32_t t_id = 0, tcount = 0;
+    uint2* plog = p.plog + (size_t)qi * p.plog_cap;
+    uint64_t tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0, tmark = 0, ngroups = 0, nhops_rows = 0;
+    uint64_t tw[3] = {0, 0, 0};
+#define ISL_MARK(acc) if (p.prof) { uint64_t now_ = __builtin_amdgcn_s_memrealtime(); acc += now_ - tmark; tmark = now_; }
+
+    // entry point: provider.compute_embedding(entry) + distance, leann.rs:911-916
+    if ((uint64_t)p.entry >= p.nvec) {
+      status = QS_NODE_NOT_FOUND;
+      payload = p.entry;
+    } else {
+      float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[p.entry] : 0.0f;
+      float ed = wave_distances<METRIC>(p.emb, p.stride, p.d, p.entry, 1, qs, tile, q_norm, e_aux);
+      ed = rl_f(ed, 0);
+      cV = 1;
+      if (lane == 0) htab[hslot(p.entry, p.hbits)] = p.entry;
+      hcount = 1;
+      rs.insert(ed, p.entry);
+      if (lane == 0) plog[0] = make_uint2(__float_as_uint(ed), p.entry);
+      cP = 1;
+      __syncthreads();
+    }
+
+    if (p.prof) tmark = __builtin_amdgcn_s_memrealtime();
+    while (status == QS_OK) {
+      // candidates.pop(): the smallest unexpanded key of R (leann.rs:922); when none is
+      // left every remaining candidate is farther than the worst result -> break (:924-928)
+      uint32_t e = rs.first_unexpanded();
+      uint32_t cid;
+      if (e != 0xFFFFFFFFu) {
+        cid = rs.id_at(e) & ID_MASK;
+        rs.mark_expanded(e);
+      } else if (tcount > 0) {
+        // every key of R is expanded; the next candidates are the tie-evicted ones, whose
+        // distance equals the worst result (`dist > worst` is false, leann.rs:925): smallest id first
+        uint32_t best = rl_u(t_id, 0);
+        int bl = 0;
+        for (uint32_t i = 1; i < tcount; ++i) {
+          uint32_t v = rl_u(t_id, (int)i);
+          if (v < best) { best = v; bl = (int)i; }
+        }
+        uint32_t last = rl_u(t_id, (int)(tcount - 1));
+        if (lane == bl) t_id = last;
+        tcount -= 1;
+        cid = best;
+      } else {
+        break;
+      }
+      if ((uint64_t)cid >= p.num_nodes) continue;  // get_neighbors -> None, leann.rs:227-229
+      uint64_t o0 = p.off[cid], o1 = p.off[cid + 1];
+      uint32_t deg = (uint32_t)(o1 - o0);
+      cH += 1;
+      cE += deg;
+      if (deg == 0) continue;
+      if (deg > 64) { status = QS_REDO; payload = 1; break; }  // long rows: exact kernel
+      bool active = (uint32_t)lane < deg;
+      uint32_t nid = active ? p.adj[o0 + lane] : EMPTY;
+
+      ISL_MARK(tp0)  // selection + adjacency fetch
+      // visited.insert(n), leann.rs:933-937 (rows hold no duplicate ids on the device)
+      if (!ovf && hcount + deg > hlimit) ovf = true;
+      bool is_new = false;
+      if (active) {
+        uint32_t h = hslot(nid, p.hbits);
+        if (!ovf) {
+          for (;;) {
+            uint32_t old = atomicCAS(&htab[h], EMPTY, nid);
+            if (old == EMPTY) { is_new = true; break; }
+            if (old == nid) break;
+            h = (h + 1) & hmask;
+          }
+        } else {
+          bool found = false;
+          for (;;) {
+            uint32_t cur = htab[h];
+            if (cur == nid) { found = true; break; }
+            if (cur == EMPTY) break;
+            h = (h + 1) & hmask;
+          }
+          if (!found) {
+            uint32_t g = hslot(nid, p.obits);
+            for (;;) {
+              uint32_t old = atomicCAS(&otab[g], EMPTY, nid);
+              if (old == EMPTY) { is_new = true; break; }
+              if (old == nid) break;
+              g = (g + 1) & omask;
+            }
+          }
+        }
+      }
+      uint64_t nm = ballot(is_new);
+      uint32_t nu = (uint32_t)__popcll(nm);
+      if (!ovf) hcount += nu;
+      else {
+        ocount += nu;
+        if (ocount > olimit) { status = QS_REDO; payload = 2; break; }
+      }
+      if (nu == 0) continue;  // leann.rs:939-941
+
+      // compact the unvisited ids, CSR order preserved
+      uint32_t rank = (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
+      if (is_new) scratch[rank] = nid;
+      __syncthreads();
+      uint32_t uid = (uint32_t)lane < nu ? scratch[lane] : 0u;
+      __syncthreads();
+
+      uint32_t keep = prune_keep(p.prune_ratio, p.prune_strategy, nu, rs.len, ef);  // :944
+      // compute_embeddings_batch, leann.rs:947: the first missing id fails the query
+      uint64_t bad = ballot((uint32_t)lane < keep && (uint64_t)uid >= p.nvec);
+      if (bad) {
+        int bl = __ffsll((long long)bad) - 1;
+        status = QS_NODE_NOT_FOUND;
+        payload = rl_u(uid, bl);
+        break;
+      }
+      cV += keep;
+      ngroups += (keep + 15) / 16;
+      nhops_rows += 1;
+      ISL_MARK(tp1)  // visited set + compaction
+      float r_aux = (METRIC == METRIC_COSINE_PRE && (uint32_t)lane < keep) ? p.norm2[uid] : 0.0f;
+      float nd = wave_distances<METRIC>(p.emb, p.stride, p.d, uid, keep, qs, tile, q_norm, r_aux,
+                                        p.prof ? tw : nullptr);
+      ISL_MARK(tp2)  // row fetch + distances
+
+      // leann.rs:953-970 in CSR order; worst = results.peek()
+      uint64_t pending = keep >= 64 ? ~0ull : ((1ull << keep) - 1ull);
+      while (pending) {
+        bool full = rs.len >= ef;
+        float worst = rs.len ? rs.dist_at(rs.len - 1) : 0.0f;
+        bool pass = !full || rs.len == 0 || nd < worst;  // raw f32 `<`, leann.rs:959
+        uint64_t pm = ballot(pass) & pending;
+        if (!pm) break;
+        int r = __ffsll((long long)pm) - 1;
+        float id_d = rl_f(nd, r);
+        uint32_t id_i = rl_u(uid, r);
+        if (cP < p.plog_cap) {
+          if (lane == 0) plog[cP] = make_uint2(__float_as_uint(id_d), id_i);
+        }
+        if (full) {
+          // results.push + pop: the old worst leaves R but stays in the reference's candidate
+          // heap.  It can only be popped again while its distance still equals the worst one.
+          float old_worst = worst;
+          uint32_t old_raw = rs.id_at(ef - 1);
+          rs.insert(id_d, id_i);
+          rs.len = ef;
+          float new_worst = rs.dist_at(ef - 1);
+          if (ordkey(old_worst) != ordkey(new_worst)) {
+            tcount = 0;
+          } else if (!(old_raw & FLAG_EXP)) {
+            if (tcount >= 64) { status = QS_REDO; payload = 3; }
+            else {
+              if (lane == (int)tcount) t_id = old_raw & ID_MASK;
+              tcount += 1;
+            }
+          }
+        } else {
+          rs.insert(id_d, id_i);
+        }
+        cP += 1;
+        pending &= ~((2ull << r) - 1ull);
+        if (r == 63) pending = 0;
+      }
+      ISL_MARK(tp3)  // result-set insertion
+    }
+
+    // results sorted by distance, take(k): leann.rs:984-986, :895
+    uint32_t outn = rs.len < p.k ? rs.len : p.k;
+    if (status == QS_OK) {
+      // equal distances inside the returned prefix (or across its boundary) are ordered by
+      // BinaryHeap array order in the reference: let the exact kernel reproduce that
+      uint32_t chk = rs.len < p.k + 1 ? rs.len : p.k + 1;
+      bool tie = false;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        uint32_t e = s * 64 + lane;
+        float nxt = __shfl_down(rs.d[s], 1);
+        if (s + 1 < S) {
+          float nd0 = rl_f(rs.d[s + 1 < S ? s + 1 : s], 0);
+          if (lane == 63) nxt = nd0;
+        }
+        if (e + 1 < chk && ordkey(rs.d[s]) == ordkey(nxt)) tie = true;
+      }
+      if (ballot(tie)) {
+        if (cP <= p.plog_cap) status = QS_REPLAY;
+        else { status = QS_REDO; payload = 4; }
+      }
+    }
+    if (status == QS_REPLAY) {
+      __threadfence_block();
+      __syncthreads();
+      float* res_d = tile;
+      uint32_t* res_i = reinterpret_cast<uint32_t*>(tile + (ef + 1));
+      uint2* stage = reinterpret_cast<uint2*>(tile + 3072);  // 12 KiB into the 16.6 KiB tile
+      replay_result_order(plog, cP, ef, p.k, qi, res_d, res_i, stage, p.out_ids, p.out_dist,
+                          p.out_count);
+      status = QS_OK;
+      outn = 0xFFFFFFFFu;  // outputs already written
+      if (lane == 0) atomicAdd(&p.ticket[3], 1u);
+    }
+    if (status == QS_OK && outn != 0xFFFFFFFFu) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        uint32_t e = s * 64 + lane;
+        if (e < outn) {
+          p.out_ids[(uint64_t)qi * p.k + e] = (uint64_t)(rs.id[s] & ID_MASK);
+          p.out_dist[(uint64_t)qi * p.k + e] = rs.d[s];
+        }
+      }
+    }
+    if (lane == 0) {
+      p.status[qi] = status;
+      // payload of a successful query: its time in the kernel (100 MHz ticks), for ISL_DEBUG
+      p.payload[qi] = status == QS_OK ? (__builtin_amdgcn_s_memrealtime() - t_start) : payload;
+      if (outn != 0xFFFFFFFFu) p.out_count[qi] = status == QS_OK ? outn : 0u;
+      p.ctr[qi * 4 + 0] = cH;
+      p.ctr[qi * 4 + 1] = cE;
+      p.ctr[qi * 4 + 2] = cV;
+      p.ctr[qi * 4 + 3] = cP;
+      if (p.prof) {
+        p.prof[qi * 8 + 0] = tp0; p.prof[qi * 8 + 1] = tp1; p.prof[qi * 8 + 2] = tp2; p.prof[qi * 8 + 3] = tp3;
+        p.prof[qi * 8 + 4] = ngroups; p.prof[qi * 8 + 5] = nhops_rows;
+        {
+          uint32_t hwid = 0, xcc = 0;
+          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+          p.prof[qi * 8 + 2] = ((uint64_t)(xcc & 0xf) << 32) | hwid;
+        }
+        p.prof[qi * 8 + 6] = tw[0]; p.prof[qi * 8 + 7] = tw[1]; p.prof[qi * 8 + 3] = tw[2];
+      }
+      if (status == QS_REDO) {
+        p.redo[atomicAdd(&p.ticket[1], 1u)] = qi;
+        // why: 1 long row, 2 visited overflow, 3 tie-candidate overflow, 0 push-log overflow
+        atomicAdd(&p.ticket[8 + ((uint32_t)payload & 3u)], 1u);
+      }
+    }
+    if (ovf) {  // leave the overflow table empty for the next query of this slot
+      for (uint32_t i = lane; i < ocap; i += 64) otab[i] = EMPTY;
+    }
+    __syncthreads();
+  }
+}
+
+// ----------------------------------------------------------------- exact kernel
+template <int METRIC_API>
 __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
+  constexpr int METRIC = METRIC_API == ISL_METRIC_COSINE ? METRIC_COSINE_PRE : METRIC_API;
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
   const uint32_t ef = p.ef;
@@ -499,7 +588,7 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
     const uint32_t qi = p.redo[t];
 
     for (uint64_t i = lane; i < p.vis_words; i += 64) vis[i] = 0u;
-    const float q_norm = load_query<METRIC>(p.queries, qi, p.d, qs);
+    const float q_norm = load_query<METRIC>(p.queries + (uint64_t)qi * p.d, p.d, qs);
     __threadfence_block();
 
     uint64_t clen = 0, rlen = 0;  // lane 0 only
@@ -511,7 +600,8 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
       status = QS_NODE_NOT_FOUND;
       payload = p.entry;
     } else {
-      float ed = wave_distances<METRIC>(p.emb, p.stride, p.d, p.entry, 1, qs, tile, q_norm);
+      float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[p.entry] : 0.0f;
+      float ed = wave_distances<METRIC>(p.emb, p.stride, p.d, p.entry, 1, qs, tile, q_norm, e_aux);
       cV = 1;
       if (lane == 0) {
         vis[p.entry >> 5] |= 1u << (p.entry & 31);
@@ -591,7 +681,8 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
       for (uint32_t base = 0; base < keep && status == QS_OK; base += 64) {
         uint32_t R = keep - base < 64 ? keep - base : 64;
         uint32_t uid = (uint32_t)lane < R ? ulist[base + lane] : 0u;
-        float nd = wave_distances<METRIC>(p.emb, p.stride, p.d, uid, R, qs, tile, q_norm);
+        float r_aux = (METRIC == METRIC_COSINE_PRE && (uint32_t)lane < R) ? p.norm2[uid] : 0.0f;
+        float nd = wave_distances<METRIC>(p.emb, p.stride, p.d, uid, R, qs, tile, q_norm, r_aux);
         if ((uint32_t)lane < R) {
           dscratch[lane] = nd;
           scratch[lane] = uid;
@@ -658,76 +749,6 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
       p.ctr[qi * 4 + 1] = cE;
       p.ctr[qi * 4 + 2] = cV;
       p.ctr[qi * 4 + 3] = cP;
-    }
-    __syncthreads();
-  }
-}
-
-// ---------------------------------------------------------------- replay kernel
-// The fast kernel's result SET is exact; only the ORDER of equal distances in the returned
-// prefix depends on Rust's BinaryHeap array layout (results.into_iter() + stable sort,
-// leann.rs:984-986).  For the few queries where such a tie shows up, this kernel replays the
-// logged sequence of results.push (and the pop that follows each push beyond ef) on an exact
-// BinaryHeap emulation and re-emits the prefix in the reference's order.  No graph or row
-// traffic: one wave per query, lane 0 sifts in LDS.
-__global__ __launch_bounds__(64) void leann_replay_order(SearchParams p) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = threadIdx.x;
-  const uint32_t ef = p.ef;
-  float* res_d = reinterpret_cast<float*>(smem);
-  uint32_t* res_i = reinterpret_cast<uint32_t*>(res_d + (ef + 1));
-  uint2* stage = reinterpret_cast<uint2*>(((uintptr_t)(res_i + (ef + 1)) + 15) & ~(uintptr_t)15);
-  uint32_t* s_len = reinterpret_cast<uint32_t*>(stage + 64);
-  for (;;) {
-    uint32_t t = 0;
-    if (lane == 0) t = atomicAdd(&p.ticket[4], 1u);
-    t = uni(t);
-    uint32_t nrep = *((volatile uint32_t*)&p.ticket[3]);
-    if (t >= nrep) break;
-    const uint32_t qi = p.replay[t];
-    const uint32_t npush = p.ctr[qi * 4 + 3];
-    const uint2* plog = p.plog + (size_t)qi * p.plog_cap;
-    uint64_t rlen = 0;
-    for (uint32_t base = 0; base < npush; base += 64) {
-      if (base + lane < npush) stage[lane] = plog[base + lane];
-      __syncthreads();
-      if (lane == 0) {
-        uint32_t cnt = npush - base < 64 ? npush - base : 64;
-        for (uint32_t i = 0; i < cnt; ++i) {
-          heap_push<ResultOrder>(res_d, res_i, rlen, __uint_as_float(stage[i].x), stage[i].y);
-          if (rlen > ef) {
-            float dd;
-            uint32_t di;
-            heap_pop<ResultOrder>(res_d, res_i, rlen, dd, di);
-          }
-        }
-      }
-      __syncthreads();
-    }
-    if (lane == 0) {
-      for (uint64_t i = 1; i < rlen; ++i) {  // stable sort by distance (partial_cmp == Less moves)
-        float d = res_d[i];
-        uint32_t id = res_i[i];
-        uint64_t j = i;
-        while (j > 0 && d < res_d[j - 1]) {
-          res_d[j] = res_d[j - 1];
-          res_i[j] = res_i[j - 1];
-          j--;
-        }
-        res_d[j] = d;
-        res_i[j] = id;
-      }
-      *s_len = (uint32_t)rlen;
-    }
-    __syncthreads();
-    uint32_t outn = *s_len < p.k ? *s_len : p.k;
-    for (uint32_t e = lane; e < outn; e += 64) {
-      p.out_ids[(uint64_t)qi * p.k + e] = (uint64_t)res_i[e];
-      p.out_dist[(uint64_t)qi * p.k + e] = res_d[e];
-    }
-    if (lane == 0) {
-      p.status[qi] = QS_OK;
-      p.out_count[qi] = outn;
     }
     __syncthreads();
   }
@@ -901,6 +922,7 @@ isl_status search_device(const isl_index* idx, const float* d_queries, uint64_t 
   p.adj = idx->d_adj;
   p.num_nodes = idx->num_nodes;
   p.emb = idx->d_emb;
+  p.norm2 = idx->d_norm2;
   p.nvec = idx->nvec;
   p.stride = idx->emb_stride;
   p.d = (uint32_t)d;
@@ -919,6 +941,12 @@ isl_status search_device(const isl_index* idx, const float* d_queries, uint64_t 
   p.ctr = ws.ctr;
   p.ticket = ws.ticket;
   p.redo = ws.redo;
+  uint64_t* d_prof = nullptr;
+  if (getenv("ISL_DEBUG")) {
+    ISL_HIP(hipMalloc(&d_prof, nq * 64));
+    ISL_HIP(hipMemset(d_prof, 0, nq * 64));
+  }
+  p.prof = d_prof;
   p.replay = ws.replay;
   p.plog = reinterpret_cast<uint2*>(ws.plog);
   p.plog_cap = plog_cap;
@@ -946,12 +974,6 @@ isl_status search_device(const isl_index* idx, const float* d_queries, uint64_t 
       default: launch_fast<8>(metric, grid, fg.lds, st, p); break;
     }
     ISL_HIP(hipGetLastError());
-    {
-      size_t rlds = (size_t)(ef + 1) * 8 + 16 + 64 * 8 + 16;
-      uint32_t rgrid = (uint32_t)std::min<uint64_t>(nq, 256);
-      launch_one(leann_replay_order, rgrid, rlds, st, p);
-      ISL_HIP(hipGetLastError());
-    }
   } else {
     // every query goes to the exact kernel: redo = [0, nq)
     std::vector<uint32_t> all(nq);
@@ -988,6 +1010,58 @@ isl_status search_device(const isl_index* idx, const float* d_queries, uint64_t 
     ss.edges += ctr[i * 4 + 1];
     ss.evals += ctr[i * 4 + 2];
     ss.pushes += ctr[i * 4 + 3];
+  }
+  if (d_prof) {
+    std::vector<uint64_t> pr(nq * 8);
+    ISL_HIP(hipMemcpy(pr.data(), d_prof, nq * 64, hipMemcpyDeviceToHost));
+    (void)hipFree(d_prof);
+    double sum[4] = {0, 0, 0, 0}, grp = 0, hr = 0;
+    for (uint64_t i = 0; i < nq; i++) {
+      for (int j = 0; j < 4; j++) sum[j] += pr[i * 8 + j] / 100.0;
+      grp += pr[i * 8 + 4];
+      hr += pr[i * 8 + 5];
+    }
+    {
+      std::map<uint64_t, int> per_simd, per_cu;
+      for (uint64_t i = 0; i < nq; i++) {
+        uint64_t v = pr[i * 8 + 2];
+        uint32_t hw = (uint32_t)v, xcc = (uint32_t)(v >> 32);
+        uint32_t simd = (hw >> 4) & 3, cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+        uint64_t cukey = ((uint64_t)xcc << 16) | (se << 8) | (sh << 4) | cu;
+        per_cu[cukey]++;
+        per_simd[(cukey << 2) | simd]++;
+      }
+      int hist_cu[16] = {0}, hist_simd[16] = {0};
+      for (auto& kv : per_cu) hist_cu[std::min(kv.second, 15)]++;
+      for (auto& kv : per_simd) hist_simd[std::min(kv.second, 15)]++;
+      fprintf(stderr, "[isl] waves per CU histogram (1..8):");
+      for (int i = 1; i <= 8; i++) fprintf(stderr, " %d", hist_cu[i]);
+      fprintf(stderr, " over %zu CUs; waves per SIMD histogram (1..4):", per_cu.size());
+      for (int i = 1; i <= 4; i++) fprintf(stderr, " %d", hist_simd[i]);
+      fprintf(stderr, "\n");
+    }
+    double w0 = 0, w1 = 0, cyc = 0;
+    for (uint64_t i = 0; i < nq; i++) { w0 += pr[i * 8 + 6] / 100.0; w1 += pr[i * 8 + 7] / 100.0; cyc += pr[i * 8 + 3]; }
+    fprintf(stderr, "[isl] consume of one piece: %.0f shader cycles -> clock %.0f MHz\n", cyc / grp, cyc / w1);
+    fprintf(stderr, "[isl] per query: %.1f hops with new rows, %.1f row groups of <=16; per group: first piece "
+            "landed+stored after %.2f us, one piece consumed in %.2f us\n", hr / nq, grp / nq, w0 / grp, w1 / grp);
+    fprintf(stderr, "[isl] mean us per query by phase: select+adjacency %.0f, visited %.0f, rows+distance %.0f, "
+            "insert %.0f\n", sum[0] / nq, sum[1] / nq, sum[2] / nq, sum[3] / nq);
+  }
+  if (getenv("ISL_DEBUG")) {
+    std::vector<uint64_t> pay(nq);
+    ISL_HIP(hipMemcpy(pay.data(), ws.payload, nq * 8, hipMemcpyDeviceToHost));
+    std::vector<double> us;
+    std::vector<std::pair<double, uint32_t>> byq;
+    for (uint64_t i = 0; i < nq; i++)
+      if (status[i] == QS_OK && pay[i]) { us.push_back(pay[i] / 100.0); byq.push_back({pay[i] / 100.0, ctr[i * 4]}); }
+    std::sort(us.begin(), us.end());
+    std::sort(byq.begin(), byq.end());
+    if (!us.empty())
+      fprintf(stderr, "[isl] per-query time in fast kernel (us): min %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f; "
+              "hops of slowest %u, of median %u; kernel %.0f us\n", us.front(), us[us.size() / 2],
+              us[us.size() * 9 / 10], us[us.size() * 99 / 100], us.back(), byq.back().second,
+              byq[byq.size() / 2].second, ms * 1000.0);
   }
   if (getenv("ISL_DEBUG") && (head[1] || head[3])) {
     fprintf(stderr, "[isl] %u of %llu queries re-run by the exact kernel (fast kernel %s): "
