@@ -400,6 +400,19 @@ class LeannIndex:
             self._h, C.c_void_p(d_queries_ptr), nq, d, k, ef, C.c_void_p(d_ids_ptr),
             C.c_void_p(d_dist_ptr), C.c_void_p(d_count_ptr), C.c_void_p(stream)))
 
+    def search_batch_device_async(self, d_queries_ptr: int, nq: int, d: int, k: int, ef: int,
+                                  d_ids_ptr: int, d_dist_ptr: int, d_count_ptr: int,
+                                  stream: int = 0) -> int:
+        """Enqueue a search; returns a token for wait().  Up to 4 may be in flight."""
+        tok = C.c_uint64()
+        _check(_ffi.lib().isl_search_batch_device_async(
+            self._h, C.c_void_p(d_queries_ptr), nq, d, k, ef, C.c_void_p(d_ids_ptr),
+            C.c_void_p(d_dist_ptr), C.c_void_p(d_count_ptr), C.c_void_p(stream), C.byref(tok)))
+        return int(tok.value)
+
+    def wait(self, token: int) -> None:
+        _check(_ffi.lib().isl_search_wait(self._h, token))
+
     def last_stats(self) -> dict:
         s = SearchStatsC()
         _check(_ffi.lib().isl_search_last_stats(self._h, C.byref(s)))

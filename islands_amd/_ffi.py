@@ -69,6 +69,9 @@ SIGNATURES = {
                                C.c_void_p, C.c_void_p]),
     "isl_search_batch_device": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "isl_search_batch_device_async": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, P(u64)]),
+    "isl_search_wait": (i32, [C.c_void_p, u64]),
     "isl_search": (i32, [C.c_void_p, C.c_void_p, u64, u64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "isl_search_last_stats": (i32, [C.c_void_p, P(SearchStatsC)]),
     "isl_distance": (i32, [i32, C.c_void_p, u64, C.c_void_p, u64, P(f32)]),

@@ -63,8 +63,13 @@ void free_workspace(SearchWorkspace& ws) {
                   ws.dist_stage, ws.count_stage};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (ws.h_status) (void)hipHostFree(ws.h_status);
+  if (ws.h_ctr) (void)hipHostFree(ws.h_ctr);
+  if (ws.h_head) (void)hipHostFree(ws.h_head);
+  if (ws.d_prof) (void)hipFree(ws.d_prof);
   if (ws.ev0) (void)hipEventDestroy(ws.ev0);
   if (ws.ev1) (void)hipEventDestroy(ws.ev1);
+  if (ws.ev_in) (void)hipEventDestroy(ws.ev_in);
   if (ws.stream) (void)hipStreamDestroy(ws.stream);
   ws = SearchWorkspace{};
 }
@@ -241,7 +246,7 @@ void isl_index_free(isl_index* idx) {
     if (idx->d_adj) (void)hipFree(idx->d_adj);
     if (idx->d_emb) (void)hipFree(idx->d_emb);
     if (idx->d_norm2) (void)hipFree(idx->d_norm2);
-    free_workspace(idx->ws);
+    for (auto& w : idx->ws) free_workspace(w);
   }
   delete idx;
 }

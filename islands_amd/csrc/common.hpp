@@ -74,8 +74,21 @@ struct SearchWorkspace {
   uint32_t* count_stage = nullptr;
   uint64_t out_stage_slots = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_in = nullptr;
+  // call in flight on this lane (isl_search_batch_device_async .. isl_search_wait)
+  bool busy = false;
+  uint64_t token = 0;
+  uint64_t nq_inflight = 0;
+  bool fast_inflight = false;
+  hipStream_t st_inflight = nullptr;
+  uint32_t* h_status = nullptr;  // pinned host mirrors of status / ctr / ticket
+  uint32_t* h_ctr = nullptr;
+  uint32_t* h_head = nullptr;
+  uint64_t h_cap = 0;
+  uint64_t* d_prof = nullptr;    // ISL_DEBUG phase timers of the call in flight
 };
+
+constexpr int kSearchLanes = 4;  // independent workspaces = searches that may be in flight
 
 }  // namespace isl
 
@@ -107,7 +120,8 @@ struct isl_index {
   uint64_t nvec = 0, emb_d = 0, emb_stride = 0;
 
   mutable std::mutex mu;  // serialises searches that share the workspace
-  mutable isl::SearchWorkspace ws;
+  mutable isl::SearchWorkspace ws[isl::kSearchLanes];
+  mutable uint64_t next_token = 1;
   mutable isl_search_stats stats{};
 };
 

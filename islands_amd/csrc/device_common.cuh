@@ -8,8 +8,9 @@
 
 namespace isl_dev {
 
-constexpr int PIECE = 256;           // floats of one row moved by one wave-instruction (1 KiB)
-constexpr int TILE_LD = PIECE + 4;   // LDS row pitch in floats: 260*r mod 64 = 4r -> conflict-free b128
+constexpr int PIECE = 128;           // floats of one row staged per step (512 B; a wave-instruction
+                                     // moves the pieces of two rows)
+constexpr int TILE_LD = PIECE + 4;   // LDS row pitch in floats: 132*r mod 64 = 4r -> conflict-free b128
 constexpr int GROUP = 16;            // rows staged together
 constexpr int TILE_ROWS = GROUP;
 constexpr int METRIC_SUMSQ = 100;   // internal: sqrt(sum x*x) (normalize_vector, distance.rs:126)
@@ -101,43 +102,48 @@ __device__ __forceinline__ float dfinish(float a0, float a1, float q_norm) {
   return a0;  // Manhattan, squared Euclidean
 }
 
-// Distances of R (<= 64) rows to the query held in LDS (`qs`); lane r < R owns row `rid` and returns
-// its distance.  Rows are handled in groups of GROUP: every wave-instruction moves one whole
-// 1-KiB piece (PIECE floats) of ONE row, fully coalesced; two pieces per row are in flight
-// (register double buffer A/B) while lanes 0..GROUP-1 run the sequential chains of the piece
-// that already sits in the LDS tile (GROUP x TILE_LD floats, conflict-free ds_read_b128).
+// Distances of R (<= 64) rows to the query held in LDS (`qs`); lane r < R owns row `rid` and
+// returns its distance.  Rows are handled in groups of GROUP = 16.  Every wave-instruction moves
+// one 512-byte piece (PIECE floats) of TWO rows, fully coalesced (32 lanes x 16 B per row);
+// three pieces per row are in flight (register ring A/B/C) while lanes 0..GROUP-1 run the
+// sequential chains of the piece that already sits in the LDS tile (GROUP x TILE_LD floats,
+// read back row-per-lane with conflict-free ds_read_b128: 132*r mod 64 = 4r).
 template <int METRIC>
 __device__ __forceinline__ float wave_distances(const float* __restrict__ emb, uint64_t stride,
                                                 uint32_t d, uint32_t rid, uint32_t R,
                                                 const float* qs, float* tile, float q_norm,
                                                 float row_aux = 0.0f, uint64_t* prof3 = nullptr) {
   const int lane = threadIdx.x;
+  const int half = lane >> 5;        // which of the two rows of a load instruction
+  const int col = (lane & 31) * 4;   // this lane's float4 inside the piece
   const uint32_t nT = (d + PIECE - 1) / PIECE;
   float result = 0.0f;
-#define ISL_FOR16(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
+#define ISL_FOR8(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7)
   for (uint32_t g0 = 0; g0 < R; g0 += GROUP) {
     const uint32_t Rg = R - g0 < (uint32_t)GROUP ? R - g0 : (uint32_t)GROUP;
-    // wave-uniform row bases (scalar registers) + this lane's 16-byte column
-#define ISL_DECL(j)                                                                        \
-  const bool on##j = (uint32_t)(j) < Rg;                                                   \
-  const float* rp##j = emb + (uint64_t)rl_u(rid, (int)((g0 + (j)) & 63)) * stride + lane * 4; \
-  float4 ra##j = make_float4(0.f, 0.f, 0.f, 0.f), rb##j = make_float4(0.f, 0.f, 0.f, 0.f),  \
+    // load instruction j serves rows 2j and 2j+1 of the group
+#define ISL_DECL(j)                                                                          \
+  const bool on##j = (uint32_t)(2 * (j) + half) < Rg;                                        \
+  const float* rp##j =                                                                       \
+      emb + (uint64_t)__shfl(rid, (int)((g0 + 2 * (j) + half) & 63)) * stride + col;         \
+  float4 ra##j = make_float4(0.f, 0.f, 0.f, 0.f), rb##j = make_float4(0.f, 0.f, 0.f, 0.f),   \
          rc##j = make_float4(0.f, 0.f, 0.f, 0.f);
-    ISL_FOR16(ISL_DECL)
+    ISL_FOR8(ISL_DECL)
 #define ISL_LOAD_A(j) if (on##j) ra##j = *reinterpret_cast<const float4*>(rp##j + poff);
 #define ISL_LOAD_B(j) if (on##j) rb##j = *reinterpret_cast<const float4*>(rp##j + poff);
 #define ISL_LOAD_C(j) if (on##j) rc##j = *reinterpret_cast<const float4*>(rp##j + poff);
-#define ISL_STORE_A(j) if (on##j) *reinterpret_cast<float4*>(tile + (j) * TILE_LD + lane * 4) = ra##j;
-#define ISL_STORE_B(j) if (on##j) *reinterpret_cast<float4*>(tile + (j) * TILE_LD + lane * 4) = rb##j;
-#define ISL_STORE_C(j) if (on##j) *reinterpret_cast<float4*>(tile + (j) * TILE_LD + lane * 4) = rc##j;
+#define ISL_STORE_A(j) \
+  if (on##j) *reinterpret_cast<float4*>(tile + (2 * (j) + half) * TILE_LD + col) = ra##j;
+#define ISL_STORE_B(j) \
+  if (on##j) *reinterpret_cast<float4*>(tile + (2 * (j) + half) * TILE_LD + col) = rb##j;
+#define ISL_STORE_C(j) \
+  if (on##j) *reinterpret_cast<float4*>(tile + (2 * (j) + half) * TILE_LD + col) = rc##j;
     float a0 = 0.0f, a1 = 0.0f;
     auto consume = [&](uint32_t t) {
-      uint64_t tl0 = (prof3 && t == 2) ? __builtin_amdgcn_s_memtime() : 0;
       if ((uint32_t)lane < Rg) {
         const float* trow = tile + lane * TILE_LD;
-        // unroll 8 keeps 16 ds_read_b128 in flight: measured sweet spot for one wave per SIMD
-        // (16.2 cycles/element; unroll 16 -> 26.5, unroll 4 -> 18.9; q through the scalar cache
-        // is faster only while the query stays in that cache, which it does not here)
+        // unroll 8 keeps 16 ds_read_b128 in flight: measured sweet spot for one wave
+        // (16.2 cycles/element; unroll 16 -> 26.5, unroll 4 -> 18.9)
         const float* qv = qs + t * PIECE;
         const uint32_t cnt = d - t * PIECE;
         if (cnt >= (uint32_t)PIECE) {
@@ -154,50 +160,47 @@ __device__ __forceinline__ float wave_distances(const float* __restrict__ emb, u
           for (uint32_t j = 0; j < cnt; ++j) dstep<METRIC>(qv[j], trow[j], a0, a1);
         }
       }
-      if (prof3 && t == 2) prof3[2] += __builtin_amdgcn_s_memtime() - tl0;
     };
-    // three pieces per row in flight: a whole 768-float row is requested at once
     uint64_t tw0 = prof3 ? __builtin_amdgcn_s_memrealtime() : 0;
     {
       const size_t poff = 0;
-      ISL_FOR16(ISL_LOAD_A)
+      ISL_FOR8(ISL_LOAD_A)
     }
     if (nT > 1) {
       const size_t poff = PIECE;
-      ISL_FOR16(ISL_LOAD_B)
+      ISL_FOR8(ISL_LOAD_B)
     }
     if (nT > 2) {
       const size_t poff = 2 * PIECE;
-      ISL_FOR16(ISL_LOAD_C)
+      ISL_FOR8(ISL_LOAD_C)
     }
     for (uint32_t t = 0; t < nT; t += 3) {
-      ISL_FOR16(ISL_STORE_A)
+      ISL_FOR8(ISL_STORE_A)
       __syncthreads();
-      uint64_t tc0 = 0;
-      if (prof3 && t == 0) { uint64_t n_ = __builtin_amdgcn_s_memrealtime(); prof3[0] += n_ - tw0; tw0 = n_; tc0 = __builtin_amdgcn_s_memtime(); }
+      if (prof3 && t == 0) { uint64_t n_ = __builtin_amdgcn_s_memrealtime(); prof3[0] += n_ - tw0; tw0 = n_; }
       if (t + 3 < nT) {
         const size_t poff = (size_t)(t + 3) * PIECE;
-        ISL_FOR16(ISL_LOAD_A)
+        ISL_FOR8(ISL_LOAD_A)
       }
       consume(t);
       __syncthreads();
-      if (prof3 && t == 0) { uint64_t n_ = __builtin_amdgcn_s_memrealtime(); prof3[1] += n_ - tw0; tw0 = n_; (void)tc0; }
+      if (prof3 && t == 0) { uint64_t n_ = __builtin_amdgcn_s_memrealtime(); prof3[1] += n_ - tw0; tw0 = n_; }
       if (t + 1 < nT) {
-        ISL_FOR16(ISL_STORE_B)
+        ISL_FOR8(ISL_STORE_B)
         __syncthreads();
         if (t + 4 < nT) {
           const size_t poff = (size_t)(t + 4) * PIECE;
-          ISL_FOR16(ISL_LOAD_B)
+          ISL_FOR8(ISL_LOAD_B)
         }
         consume(t + 1);
         __syncthreads();
       }
       if (t + 2 < nT) {
-        ISL_FOR16(ISL_STORE_C)
+        ISL_FOR8(ISL_STORE_C)
         __syncthreads();
         if (t + 5 < nT) {
           const size_t poff = (size_t)(t + 5) * PIECE;
-          ISL_FOR16(ISL_LOAD_C)
+          ISL_FOR8(ISL_LOAD_C)
         }
         consume(t + 2);
         __syncthreads();
@@ -211,12 +214,12 @@ __device__ __forceinline__ float wave_distances(const float* __restrict__ emb, u
 #undef ISL_DECL
 #undef ISL_LOAD_A
 #undef ISL_LOAD_B
+#undef ISL_LOAD_C
 #undef ISL_STORE_A
 #undef ISL_STORE_B
-#undef ISL_LOAD_C
 #undef ISL_STORE_C
   }
-#undef ISL_FOR16
+#undef ISL_FOR8
   return result;
 }
 

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
   const int lane = threadIdx.x;
   const uint32_t hcap = 1u << p.hbits;
   const uint32_t hmask = hcap - 1;
-  const uint32_t hlimit = hcap - hcap / 4;  // load factor 0.75
+  const uint32_t hlimit = hcap - hcap / 8;  // load factor 0.875
   uint32_t* htab = reinterpret_cast<uint32_t*>(smem);
   float* tile = reinterpret_cast<float*>(smem + (size_t)hcap * 4);
   uint32_t* scratch = reinterpret_cast<uint32_t*>(tile + TILE_ROWS * TILE_LD);
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       __syncthreads();
       float* res_d = tile;
       uint32_t* res_i = reinterpret_cast<uint32_t*>(tile + (ef + 1));
-      uint2* stage = reinterpret_cast<uint2*>(tile + 3072);  // 12 KiB into the 16.6 KiB tile
+      uint2* stage = reinterpret_cast<uint2*>(tile + 1280);  // 5 KiB into the 8.25 KiB tile
       replay_result_order(plog, cP, ef, p.k, qi, res_d, res_i, stage, p.out_ids, p.out_dist,
                           p.out_count);
       status = QS_OK;
@@ -762,7 +762,7 @@ struct FastGeom {
 
 FastGeom fast_geometry(uint32_t ef, uint32_t d) {
   // visited capacity grows with ef (V is roughly 10-30 x ef); overflow goes to HBM
-  uint32_t hbits = ef <= 32 ? 10 : ef <= 64 ? 11 : ef <= 160 ? 12 : ef <= 320 ? 13 : 14;
+  uint32_t hbits = ef <= 64 ? 10 : ef <= 160 ? 11 : ef <= 320 ? 12 : 13;
   size_t lds = ((size_t)4 << hbits) + (size_t)TILE_ROWS * TILE_LD * 4 + 64 * 4 +
                (size_t)((d + 3) / 4 * 4) * 4;
   return {hbits, lds};
@@ -806,8 +806,8 @@ __global__ void fill_u32_kernel(uint32_t* p, uint64_t n, uint32_t v) {
   for (; i < n; i += stride) p[i] = v;
 }
 
-constexpr uint32_t kExactSlots = 128;
-constexpr uint32_t kOvfBits = 16;
+constexpr uint32_t kExactSlots = 32;
+constexpr uint32_t kOvfBits = 15;
 constexpr uint32_t kMaxExactEf = 4096;
 
 template <typename T>
@@ -821,13 +821,25 @@ isl_status ensure(T*& ptr, uint64_t& have, uint64_t want) {
   return ISL_OK;
 }
 
-isl_status prepare_workspace(const isl_index* idx, uint32_t nq, uint32_t slots, uint32_t plog_cap) {
-  isl::SearchWorkspace& ws = idx->ws;
+isl_status prepare_workspace(isl::SearchWorkspace& ws, uint32_t nq, uint32_t slots,
+                             uint32_t plog_cap) {
   if (!ws.stream) {
     ISL_HIP(hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking));
     ISL_HIP(hipEventCreate(&ws.ev0));
     ISL_HIP(hipEventCreate(&ws.ev1));
+    ISL_HIP(hipEventCreateWithFlags(&ws.ev_in, hipEventDisableTiming));
     ISL_HIP(hipMalloc(&ws.ticket, 64));
+    ISL_HIP(hipHostMalloc(&ws.h_head, 64));
+  }
+  if (ws.h_cap < nq) {
+    if (ws.h_status) (void)hipHostFree(ws.h_status);
+    if (ws.h_ctr) (void)hipHostFree(ws.h_ctr);
+    ws.h_status = ws.h_ctr = nullptr;
+    ws.h_cap = 0;
+    uint64_t cap = nq < 1024 ? 1024 : nq;
+    ISL_HIP(hipHostMalloc(&ws.h_status, cap * 4));
+    ISL_HIP(hipHostMalloc(&ws.h_ctr, cap * 16));
+    ws.h_cap = cap;
   }
   if (ws.slots < slots || !ws.ovf_tab) {
     if (ws.ovf_tab) (void)hipFree(ws.ovf_tab);
@@ -866,11 +878,10 @@ isl_status prepare_workspace(const isl_index* idx, uint32_t nq, uint32_t slots, 
   return ISL_OK;
 }
 
-isl_status prepare_exact(const isl_index* idx) {
-  isl::SearchWorkspace& ws = idx->ws;
+isl_status prepare_exact(const isl_index* idx, isl::SearchWorkspace& ws) {
   uint64_t max_id = std::max(idx->num_nodes, idx->nvec);
   uint64_t words = (max_id + 31) / 32 + 1;
-  uint64_t cand_cap = std::min<uint64_t>(max_id + 1, 1ull << 22);
+  uint64_t cand_cap = std::min<uint64_t>(max_id + 1, 1ull << 21);
   uint32_t ucap = std::max<uint32_t>(idx->max_degree, 64);
   if (ws.exact_slots == kExactSlots && ws.vis_words >= words && ws.cand_cap >= cand_cap &&
       ws.ulist_cap >= ucap)
@@ -891,11 +902,18 @@ isl_status prepare_exact(const isl_index* idx) {
   return ISL_OK;
 }
 
-// Core of both entry points: every pointer is a device pointer.
-isl_status search_device(const isl_index* idx, const float* d_queries, uint64_t nq, uint64_t d,
-                         uint64_t k, uint64_t ef_in, uint64_t* d_ids, float* d_dist,
-                         uint32_t* d_count, hipStream_t user_stream, bool use_own_stream) {
-  isl::SearchWorkspace& ws = idx->ws;
+// Stream a call runs on.  OWN: the lane's non-blocking stream (host-pointer entry point).
+// USER: the caller's stream (NULL = legacy default stream, ordered after the caller's earlier
+// work on it, e.g. torch kernels that produced the queries).  OWN_AFTER_USER: the lane's stream,
+// made to wait for everything already enqueued on the caller's stream -- lets several searches
+// overlap (asynchronous entry point).
+enum class StreamMode { OWN, USER, OWN_AFTER_USER };
+
+// Enqueues the kernels of one search on a free lane; every pointer is a device pointer.
+isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const float* d_queries,
+                          uint64_t nq, uint64_t d, uint64_t k, uint64_t ef_in, uint64_t* d_ids,
+                          float* d_dist, uint32_t* d_count, hipStream_t user_stream,
+                          StreamMode mode) {
   const uint32_t ef = (uint32_t)std::max(ef_in, k);  // leann.rs:890
   if (ef > kMaxExactEf)
     return isl::fail(ISL_ERR_UNSUPPORTED, "ef = %u exceeds the device limit %u", ef, kMaxExactEf);
@@ -911,11 +929,13 @@ isl_status search_device(const isl_index* idx, const float* d_queries, uint64_t 
   if (per_cu == 0) use_fast = false;
   uint32_t slots = std::max<uint32_t>(1, (uint32_t)ncu * std::max<uint32_t>(per_cu, 1));
   const uint32_t plog_cap = std::max<uint32_t>(1024, 12 * ef);  // pushes per query ~ 3-6 x ef
-  ISL_TRY(prepare_workspace(idx, (uint32_t)nq, slots, plog_cap));
-  ISL_TRY(prepare_exact(idx));
-  // device entry point: NULL means the legacy default stream, which is ordered after the
-  // caller's earlier work on it (e.g. torch kernels that produced the queries)
-  hipStream_t st = use_own_stream ? ws.stream : user_stream;
+  ISL_TRY(prepare_workspace(ws, (uint32_t)nq, slots, plog_cap));
+  ISL_TRY(prepare_exact(idx, ws));
+  hipStream_t st = mode == StreamMode::USER ? user_stream : ws.stream;
+  if (mode == StreamMode::OWN_AFTER_USER) {
+    ISL_HIP(hipEventRecord(ws.ev_in, user_stream));
+    ISL_HIP(hipStreamWaitEvent(ws.stream, ws.ev_in, 0));
+  }
 
   SearchParams p{};
   p.off = idx->d_off;
@@ -941,12 +961,12 @@ isl_status search_device(const isl_index* idx, const float* d_queries, uint64_t 
   p.ctr = ws.ctr;
   p.ticket = ws.ticket;
   p.redo = ws.redo;
-  uint64_t* d_prof = nullptr;
+  if (ws.d_prof) { (void)hipFree(ws.d_prof); ws.d_prof = nullptr; }
   if (getenv("ISL_DEBUG")) {
-    ISL_HIP(hipMalloc(&d_prof, nq * 64));
-    ISL_HIP(hipMemset(d_prof, 0, nq * 64));
+    ISL_HIP(hipMalloc(&ws.d_prof, nq * 64));
+    ISL_HIP(hipMemset(ws.d_prof, 0, nq * 64));
   }
-  p.prof = d_prof;
+  p.prof = ws.d_prof;
   p.replay = ws.replay;
   p.plog = reinterpret_cast<uint2*>(ws.plog);
   p.plog_cap = plog_cap;
@@ -990,12 +1010,29 @@ isl_status search_device(const isl_index* idx, const float* d_queries, uint64_t 
   }
   ISL_HIP(hipEventRecord(ws.ev1, st));
 
-  std::vector<uint32_t> status(nq), ctr(nq * 4);
-  uint32_t head[16];
-  ISL_HIP(hipMemcpyAsync(status.data(), ws.status, nq * 4, hipMemcpyDeviceToHost, st));
-  ISL_HIP(hipMemcpyAsync(ctr.data(), ws.ctr, nq * 16, hipMemcpyDeviceToHost, st));
-  ISL_HIP(hipMemcpyAsync(head, ws.ticket, 64, hipMemcpyDeviceToHost, st));
-  ISL_HIP(hipStreamSynchronize(st));
+  ISL_HIP(hipMemcpyAsync(ws.h_status, ws.status, nq * 4, hipMemcpyDeviceToHost, st));
+  ISL_HIP(hipMemcpyAsync(ws.h_ctr, ws.ctr, nq * 16, hipMemcpyDeviceToHost, st));
+  ISL_HIP(hipMemcpyAsync(ws.h_head, ws.ticket, 64, hipMemcpyDeviceToHost, st));
+  ws.busy = true;
+  ws.nq_inflight = nq;
+  ws.fast_inflight = use_fast;
+  ws.st_inflight = st;
+  return ISL_OK;
+}
+
+// Waits for the call in flight on `ws`, folds its counters into the index statistics and turns
+// per-query failures into the CoreError the reference's sequential map would have returned.
+isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws) {
+  if (!ws.busy) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "no search in flight for this token");
+  ws.busy = false;
+  const uint64_t nq = ws.nq_inflight;
+  const bool use_fast = ws.fast_inflight;
+  ISL_HIP(hipStreamSynchronize(ws.st_inflight));
+  const uint32_t* status = ws.h_status;
+  const uint32_t* ctr = ws.h_ctr;
+  const uint32_t* head = ws.h_head;
+  uint64_t* d_prof = ws.d_prof;
+  ws.d_prof = nullptr;
   float ms = 0.0f;
   (void)hipEventElapsedTime(&ms, ws.ev0, ws.ev1);
 
@@ -1124,6 +1161,13 @@ isl_status precheck(const isl_index* idx, uint64_t nq, uint64_t d, uint64_t k, u
 
 extern "C" {
 
+// picks a lane with no call in flight (under idx->mu)
+static isl::SearchWorkspace* free_lane(const isl_index* idx) {
+  for (auto& w : idx->ws)
+    if (!w.busy) return &w;
+  return nullptr;
+}
+
 isl_status isl_search_batch_device(const isl_index* idx, const float* d_queries, uint64_t nq,
                                    uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_out_ids,
                                    float* d_out_dist, uint32_t* d_out_count, void* stream) {
@@ -1134,8 +1178,46 @@ isl_status isl_search_batch_device(const isl_index* idx, const float* d_queries,
     return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
   ISL_TRY(isl::use_device(idx->device));
   std::lock_guard<std::mutex> lock(idx->mu);
-  return search_device(idx, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count,
-                       (hipStream_t)stream, false);
+  isl::SearchWorkspace* ws = free_lane(idx);
+  if (!ws) return isl::fail(ISL_ERR_SEARCH, "Search error: every search lane has a call in flight");
+  ISL_TRY(search_enqueue(idx, *ws, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count,
+                         (hipStream_t)stream, StreamMode::USER));
+  return search_finish(idx, *ws);
+}
+
+isl_status isl_search_batch_device_async(const isl_index* idx, const float* d_queries, uint64_t nq,
+                                         uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_out_ids,
+                                         float* d_out_dist, uint32_t* d_out_count, void* stream,
+                                         uint64_t* token) {
+  if (!token) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "token is NULL");
+  *token = 0;
+  int done = 0;
+  ISL_TRY(precheck(idx, nq, d, k, d_out_count, true, &done));
+  if (done == 1) return ISL_OK;  // token 0: nothing to wait for
+  if (!d_queries || !d_out_count || (k && (!d_out_ids || !d_out_dist)))
+    return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
+  ISL_TRY(isl::use_device(idx->device));
+  std::lock_guard<std::mutex> lock(idx->mu);
+  isl::SearchWorkspace* ws = free_lane(idx);
+  if (!ws)
+    return isl::fail(ISL_ERR_SEARCH,
+                     "Search error: %d searches already in flight; isl_search_wait one first",
+                     isl::kSearchLanes);
+  ISL_TRY(search_enqueue(idx, *ws, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count,
+                         (hipStream_t)stream, StreamMode::OWN_AFTER_USER));
+  ws->token = idx->next_token++;
+  *token = ws->token;
+  return ISL_OK;
+}
+
+isl_status isl_search_wait(const isl_index* idx, uint64_t token) {
+  if (!idx) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "index is NULL");
+  if (token == 0) return ISL_OK;
+  ISL_TRY(isl::use_device(idx->device));
+  std::lock_guard<std::mutex> lock(idx->mu);
+  for (auto& w : idx->ws)
+    if (w.busy && w.token == token) return search_finish(idx, w);
+  return isl::fail(ISL_ERR_INVALID_ARGUMENT, "unknown or already completed search token");
 }
 
 isl_status isl_search_batch(const isl_index* idx, const float* queries, uint64_t nq, uint64_t d,
@@ -1148,7 +1230,9 @@ isl_status isl_search_batch(const isl_index* idx, const float* queries, uint64_t
     return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
   ISL_TRY(isl::use_device(idx->device));
   std::lock_guard<std::mutex> lock(idx->mu);
-  isl::SearchWorkspace& ws = idx->ws;
+  isl::SearchWorkspace* wsp = free_lane(idx);
+  if (!wsp) return isl::fail(ISL_ERR_SEARCH, "Search error: every search lane has a call in flight");
+  isl::SearchWorkspace& ws = *wsp;
   uint64_t qbytes = nq * d * 4;
   if (ws.q_stage_bytes < qbytes) {
     if (ws.q_stage) (void)hipFree(ws.q_stage);
@@ -1170,8 +1254,9 @@ isl_status isl_search_batch(const isl_index* idx, const float* queries, uint64_t
     ws.out_stage_slots = slots;
   }
   ISL_HIP(hipMemcpy(ws.q_stage, queries, qbytes, hipMemcpyHostToDevice));
-  ISL_TRY(search_device(idx, ws.q_stage, nq, d, k, ef, ws.ids_stage, ws.dist_stage,
-                        ws.count_stage, nullptr, true));
+  ISL_TRY(search_enqueue(idx, ws, ws.q_stage, nq, d, k, ef, ws.ids_stage, ws.dist_stage,
+                         ws.count_stage, nullptr, StreamMode::OWN));
+  ISL_TRY(search_finish(idx, ws));
   if (k) {
     ISL_HIP(hipMemcpy(out_ids, ws.ids_stage, nq * k * 8, hipMemcpyDeviceToHost));
     ISL_HIP(hipMemcpy(out_dist, ws.dist_stage, nq * k * 4, hipMemcpyDeviceToHost));

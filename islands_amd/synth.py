@@ -240,8 +240,13 @@ def _lloyd_centroids(x, n_cent, iters=3, seed=11, chunk=1 << 18, ids=None):
         for s0 in range(0, n, chunk):
             xb = x[s0:s0 + chunk]
             a = torch.argmax(xb.to(torch.bfloat16) @ Ch.T, dim=1)
-            sums.index_add_(0, a, xb)
-            cnt.index_add_(0, a, torch.ones_like(a, dtype=torch.float32))
+            # deterministic segmented sums (index_add_ uses float atomics: run-to-run noise
+            # would change the buckets and with them the graph)
+            order = torch.argsort(a, stable=True)
+            lens = torch.bincount(a, minlength=n_cent)
+            part = torch.segment_reduce(xb[order], "sum", lengths=lens, unsafe=True)
+            sums += part
+            cnt += lens.to(torch.float32)
         alive = cnt > 0
         newC = sums / sums.norm(dim=1, keepdim=True).clamp_min(1e-20)
         C = torch.where(alive[:, None], newC, C)
@@ -343,7 +348,7 @@ def _nearest_parent(x, child_ids, parent_ids, npar=2, chunk=1 << 16):
 
 
 @torch.no_grad()
-def build_graph(x: torch.Tensor, m0: int = 60, k0: int = 28, k_upper: int = 16, pool: int = 64,
+def build_graph(x: torch.Tensor, m0: int = 60, k0: int = 28, k_upper: int = 20, pool: int = 96,
                 child_cap: int = 30, seed: int = 7, level_ratio: int = 32):
     """Flattened hierarchical proximity graph over the rows of x (L2-normalised, cosine).
     Returns (offsets int64 [n+1], neighbours int32 [nnz], entry_point int).
