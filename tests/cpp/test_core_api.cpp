@@ -1,0 +1,108 @@
+// C++ mirror of the reference's inline tests for the path (src/core/leann.rs:1089-1572,
+// src/core/distance.rs:148-440), written against include/islands_amd.hpp.
+// `test_core_api cpu` runs the host-only part; `test_core_api gpu` adds the device part.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+#include "islands_amd.hpp"
+
+using namespace islands::core;
+
+static int failures = 0;
+#define EXPECT(cond)                                                        \
+  do {                                                                      \
+    if (!(cond)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); failures++; } \
+  } while (0)
+
+template <class F>
+static bool throws(isl_status st, F f) {
+  try { f(); } catch (const CoreError& e) { return e.status == st; }
+  return false;
+}
+
+static std::vector<float> random_vectors(size_t n, size_t d, unsigned seed) {  // leann.rs:1078-1083 shape
+  std::mt19937 rng(seed);
+  std::uniform_real_distribution<float> u(-1.f, 1.f);
+  std::vector<float> v(n * d);
+  for (auto& x : v) x = u(rng);
+  return v;
+}
+
+static void test_config() {  // leann.rs:1091-1143
+  LeannConfig c = LeannConfig::paper_default();
+  EXPECT(c.m == 30 && c.m0 == 60 && c.ef_construction == 128 && c.ef_search == 64);
+  EXPECT(c.is_compact && c.is_recompute && c.high_degree_pruning);
+  EXPECT(std::fabs(c.hub_percentile - 0.02f) < 1e-3f);
+  c.validate();
+  EXPECT(LeannConfig::fast().prune_ratio > 0 && LeannConfig::fast().m < 30);
+  EXPECT(LeannConfig::accurate().m > 30 && LeannConfig::accurate().ef_construction > 128);
+  LeannConfig bad; bad.m = 0;
+  EXPECT(throws(ISL_ERR_INVALID_CONFIG, [&] { bad.validate(); }));
+  bad = LeannConfig(); bad.m0 = 16;
+  EXPECT(throws(ISL_ERR_INVALID_CONFIG, [&] { bad.validate(); }));
+  bad = LeannConfig(); bad.prune_ratio = 1.5f;
+  EXPECT(throws(ISL_ERR_INVALID_CONFIG, [&] { bad.validate(); }));
+  bad = LeannConfig(); bad.beam_width = 0;
+  EXPECT(throws(ISL_ERR_INVALID_CONFIG, [&] { bad.validate(); }));
+}
+
+static void test_csr_and_bytes() {  // leann.rs:1171-1217, 1347-1384
+  CsrGraph g;
+  EXPECT(g.num_nodes == 0 && !g.entry_point);
+  EXPECT(g.add_node({}, 0) == 0 && *g.entry_point == 0);
+  EXPECT(g.add_node({0}, 1) == 1 && *g.entry_point == 1);
+  g.add_node({0, 1}, 0);
+  EXPECT(g.get_neighbors(2)->second == 2 && !g.get_neighbors(999));
+  LeannIndex idx = LeannIndex::from_csr(g, LeannConfig(), 16);
+  EXPECT(idx.len() == 3 && *idx.dimension() == 16 && idx.storage_bytes() == g.storage_bytes());
+  auto bytes = idx.to_bytes();
+  LeannIndex r = LeannIndex::from_bytes(bytes);
+  EXPECT(r.len() == idx.len() && r.dimension() == idx.dimension() && r.to_bytes() == bytes);
+  bytes.resize(40);
+  EXPECT(throws(ISL_ERR_DESERIALIZATION, [&] { LeannIndex::from_bytes(bytes); }));
+  LeannIndex e = LeannIndex::with_defaults();  // leann.rs:1259-1267
+  EXPECT(e.is_empty() && e.len() == 0 && !e.dimension() && e.is_recompute() && e.is_compact());
+  EXPECT(throws(ISL_ERR_DIMENSION_MISMATCH, [&] { calculate(DistanceMetric::Cosine, {1, 2}, {1, 2, 3}); }));
+}
+
+static void test_gpu() {
+  // distance.rs:150-229
+  EXPECT(std::fabs(calculate(DistanceMetric::Cosine, {1, 2, 3}, {1, 2, 3})) < 1e-6f);
+  EXPECT(std::fabs(calculate(DistanceMetric::Cosine, {1, 0}, {0, 1}) - 1.f) < 1e-6f);
+  EXPECT(std::fabs(calculate(DistanceMetric::Euclidean, {0, 0}, {3, 4}) - 5.f) < 1e-6f);
+  EXPECT(calculate(DistanceMetric::Manhattan, {0, 0}, {3, 4}) == 7.f);
+  EXPECT(calculate(DistanceMetric::Cosine, {0, 0, 0}, {1, 2, 3}) == 1.f);
+  EXPECT(std::fabs(calculate(DistanceMetric::DotProduct, {1, 2, 3}, {4, 5, 6}) + 32.f) < 1e-6f);
+  EXPECT(std::fabs(calculate_squared(DistanceMetric::Euclidean, {0, 0}, {3, 4}) - 25.f) < 1e-6f);
+  auto b = batch_calculate(DistanceMetric::Cosine, {1, 0}, {1, 0, 0, 1, -1, 0}, 2);
+  EXPECT(b.size() == 3 && std::fabs(b[0]) < 1e-6f && std::fabs(b[1] - 1) < 1e-6f && std::fabs(b[2] - 2) < 1e-6f);
+
+  // a ring graph with chords: self-query returns id 0 at distance ~0, ascending order, k results
+  const size_t n = 100, d = 16;
+  auto vecs = random_vectors(n, d, 42);
+  CsrGraph g;
+  for (size_t i = 0; i < n; i++)
+    g.add_node({(i + 1) % n, (i + n - 1) % n, (i + 7) % n, (i * 13 + 5) % n == i ? (i + 3) % n : (i * 13 + 5) % n}, 0);
+  g.entry_point = 0;
+  LeannIndex idx = LeannIndex::from_csr(g, LeannConfig(), d);
+  idx.upload(0);
+  idx.attach(InMemoryEmbeddingProvider(vecs, d));
+  std::vector<float> q(vecs.begin(), vecs.begin() + d);
+  auto res = idx.search_with_params(q, 5, 200);  // leann.rs:1290-1304
+  EXPECT(res.size() == 5 && res[0].first == 0 && res[0].second < 0.01f);
+  for (size_t i = 1; i < res.size(); i++) EXPECT(res[i - 1].second <= res[i].second);  // :1327-1343
+  EXPECT(throws(ISL_ERR_DIMENSION_MISMATCH, [&] { idx.search(std::vector<float>(8, 0.5f), 5); }));  // :1315-1325
+  LeannIndex empty = LeannIndex::with_defaults();  // :1306-1313
+  EXPECT(empty.search(std::vector<float>(8, 0.5f), 5).empty());
+}
+
+int main(int argc, char** argv) {
+  bool gpu = argc > 1 && !std::strcmp(argv[1], "gpu");
+  test_config();
+  test_csr_and_bytes();
+  if (gpu) test_gpu();
+  std::printf("%s: %d failure(s)\n", gpu ? "cpu+gpu" : "cpu", failures);
+  return failures ? 1 : 0;
+}
