@@ -27,6 +27,12 @@ __device__ __forceinline__ uint32_t rl_u(uint32_t v, int lane) {
 __device__ __forceinline__ float rl_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+// lane i receives the value of lane i-1 (lane 0 keeps `v`): DPP wave_shr:1, a plain VALU move
+// on gfx9-family parts, instead of the LDS-crossbar round trip of __shfl_up.
+__device__ __forceinline__ uint32_t shr1_u(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float shr1_f(float v) { return __uint_as_float(shr1_u(__float_as_uint(v))); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
@@ -102,115 +108,108 @@ __device__ __forceinline__ float dfinish(float a0, float a1, float q_norm) {
   return a0;  // Manhattan, squared Euclidean
 }
 
-// Distances of R (<= 64) rows to the query held in LDS (`qs`); lane r < R owns row `rid` and
-// returns its distance.  Rows are handled in groups of GROUP = 16.  Every wave-instruction moves
-// one 512-byte piece (PIECE floats) of TWO rows, fully coalesced (32 lanes x 16 B per row);
-// three pieces per row are in flight (register ring A/B/C) while lanes 0..GROUP-1 run the
-// sequential chains of the piece that already sits in the LDS tile (GROUP x TILE_LD floats,
-// read back row-per-lane with conflict-free ds_read_b128: 132*r mod 64 = 4r).
-template <int METRIC>
-__device__ __forceinline__ float wave_distances(const float* __restrict__ emb, uint64_t stride,
-                                                uint32_t d, uint32_t rid, uint32_t R,
-                                                const float* qs, float* tile, float q_norm,
-                                                float row_aux = 0.0f, uint64_t* prof3 = nullptr) {
+// One group of Rg <= 2*NI rows (NI = load instructions per piece, compile-time).  Every
+// wave-instruction moves one 512-byte piece (PIECE floats) of TWO rows, fully coalesced
+// (32 lanes x 16 B per row); three pieces per row are in flight (register ring A/B/C) while
+// lanes 0..Rg-1 run the sequential chains of the piece that already sits in the LDS tile
+// (GROUP x TILE_LD floats, read back row-per-lane with conflict-free ds_read_b128:
+// 132*r mod 64 = 4r).  All loads and LDS stores of a variant are unconditional straight-line
+// code -- a predicate per instruction makes hipcc fall back to s_waitcnt vmcnt(0) before every
+// store, which serialises the ring; lanes whose row does not exist re-read the group's first
+// row (same cache lines) into a tile row that no lane consumes.
+template <int METRIC, int NI>
+__device__ __forceinline__ float group_distances(const float* __restrict__ emb, uint64_t stride,
+                                                 uint32_t d, uint32_t rid, uint32_t g0, uint32_t Rg,
+                                                 const float* qs, float* tile, float q_norm,
+                                                 float row_aux, uint64_t* prof3) {
   const int lane = threadIdx.x;
   const int half = lane >> 5;        // which of the two rows of a load instruction
   const int col = (lane & 31) * 4;   // this lane's float4 inside the piece
   const uint32_t nT = (d + PIECE - 1) / PIECE;
-  float result = 0.0f;
 #define ISL_FOR8(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7)
-  for (uint32_t g0 = 0; g0 < R; g0 += GROUP) {
-    const uint32_t Rg = R - g0 < (uint32_t)GROUP ? R - g0 : (uint32_t)GROUP;
-    // load instruction j serves rows 2j and 2j+1 of the group
 #define ISL_DECL(j)                                                                          \
-  const bool on##j = (uint32_t)(2 * (j) + half) < Rg;                                        \
-  const float* rp##j =                                                                       \
-      emb + (uint64_t)__shfl(rid, (int)((g0 + 2 * (j) + half) & 63)) * stride + col;         \
-  float4 ra##j = make_float4(0.f, 0.f, 0.f, 0.f), rb##j = make_float4(0.f, 0.f, 0.f, 0.f),   \
-         rc##j = make_float4(0.f, 0.f, 0.f, 0.f);
-    ISL_FOR8(ISL_DECL)
-#define ISL_LOAD_A(j) if (on##j) ra##j = *reinterpret_cast<const float4*>(rp##j + poff);
-#define ISL_LOAD_B(j) if (on##j) rb##j = *reinterpret_cast<const float4*>(rp##j + poff);
-#define ISL_LOAD_C(j) if (on##j) rc##j = *reinterpret_cast<const float4*>(rp##j + poff);
+  const uint32_t rw##j = (uint32_t)(2 * (j) + half) < Rg ? (uint32_t)(2 * (j) + half) : 0u;  \
+  const float* rp##j = emb + (uint64_t)__shfl(rid, (int)((g0 + rw##j) & 63)) * stride + col; \
+  float4 ra##j = make_float4(0.f, 0.f, 0.f, 0.f), rb##j = ra##j, rc##j = ra##j;
+  ISL_FOR8(ISL_DECL)
+#define ISL_LOAD_A(j) if constexpr ((j) < NI) ra##j = *reinterpret_cast<const float4*>(rp##j + poff);
+#define ISL_LOAD_B(j) if constexpr ((j) < NI) rb##j = *reinterpret_cast<const float4*>(rp##j + poff);
+#define ISL_LOAD_C(j) if constexpr ((j) < NI) rc##j = *reinterpret_cast<const float4*>(rp##j + poff);
 #define ISL_STORE_A(j) \
-  if (on##j) *reinterpret_cast<float4*>(tile + (2 * (j) + half) * TILE_LD + col) = ra##j;
+  if constexpr ((j) < NI) *reinterpret_cast<float4*>(tile + (2 * (j) + half) * TILE_LD + col) = ra##j;
 #define ISL_STORE_B(j) \
-  if (on##j) *reinterpret_cast<float4*>(tile + (2 * (j) + half) * TILE_LD + col) = rb##j;
+  if constexpr ((j) < NI) *reinterpret_cast<float4*>(tile + (2 * (j) + half) * TILE_LD + col) = rb##j;
 #define ISL_STORE_C(j) \
-  if (on##j) *reinterpret_cast<float4*>(tile + (2 * (j) + half) * TILE_LD + col) = rc##j;
-    float a0 = 0.0f, a1 = 0.0f;
-    auto consume = [&](uint32_t t) {
-      if ((uint32_t)lane < Rg) {
-        const float* trow = tile + lane * TILE_LD;
-        // unroll 8 keeps 16 ds_read_b128 in flight: measured sweet spot for one wave
-        // (16.2 cycles/element; unroll 16 -> 26.5, unroll 4 -> 18.9)
-        const float* qv = qs + t * PIECE;
-        const uint32_t cnt = d - t * PIECE;
-        if (cnt >= (uint32_t)PIECE) {
+  if constexpr ((j) < NI) *reinterpret_cast<float4*>(tile + (2 * (j) + half) * TILE_LD + col) = rc##j;
+  float a0 = 0.0f, a1 = 0.0f;
+  auto consume = [&](uint32_t t) {
+    if ((uint32_t)lane < Rg) {
+      const float* trow = tile + lane * TILE_LD;
+      // unroll 8 keeps 16 ds_read_b128 in flight: measured sweet spot for one wave
+      // (16.2 cycles/element; unroll 16 -> 26.5, unroll 4 -> 18.9)
+      const float* qv = qs + t * PIECE;
+      const uint32_t cnt = d - t * PIECE;
+      if (cnt >= (uint32_t)PIECE) {
 #pragma unroll 8
-          for (int j = 0; j < PIECE; j += 4) {
-            float4 x = *reinterpret_cast<const float4*>(trow + j);
-            float4 q = *reinterpret_cast<const float4*>(qv + j);
-            dstep<METRIC>(q.x, x.x, a0, a1);
-            dstep<METRIC>(q.y, x.y, a0, a1);
-            dstep<METRIC>(q.z, x.z, a0, a1);
-            dstep<METRIC>(q.w, x.w, a0, a1);
-          }
-        } else {
-          for (uint32_t j = 0; j < cnt; ++j) dstep<METRIC>(qv[j], trow[j], a0, a1);
+        for (int j = 0; j < PIECE; j += 4) {
+          float4 x = *reinterpret_cast<const float4*>(trow + j);
+          float4 q = *reinterpret_cast<const float4*>(qv + j);
+          dstep<METRIC>(q.x, x.x, a0, a1);
+          dstep<METRIC>(q.y, x.y, a0, a1);
+          dstep<METRIC>(q.z, x.z, a0, a1);
+          dstep<METRIC>(q.w, x.w, a0, a1);
         }
+      } else {
+        for (uint32_t j = 0; j < cnt; ++j) dstep<METRIC>(qv[j], trow[j], a0, a1);
       }
-    };
-    uint64_t tw0 = prof3 ? __builtin_amdgcn_s_memrealtime() : 0;
-    {
-      const size_t poff = 0;
+    }
+  };
+  uint64_t tw0 = prof3 ? __builtin_amdgcn_s_memrealtime() : 0;
+  {
+    const size_t poff = 0;
+    ISL_FOR8(ISL_LOAD_A)
+  }
+  if (nT > 1) {
+    const size_t poff = PIECE;
+    ISL_FOR8(ISL_LOAD_B)
+  }
+  if (nT > 2) {
+    const size_t poff = 2 * PIECE;
+    ISL_FOR8(ISL_LOAD_C)
+  }
+  for (uint32_t t = 0; t < nT; t += 3) {
+    ISL_FOR8(ISL_STORE_A)
+    __syncthreads();
+    if (prof3 && t == 0) { uint64_t n_ = __builtin_amdgcn_s_memrealtime(); prof3[0] += n_ - tw0; tw0 = n_; }
+    if (t + 3 < nT) {
+      const size_t poff = (size_t)(t + 3) * PIECE;
       ISL_FOR8(ISL_LOAD_A)
     }
-    if (nT > 1) {
-      const size_t poff = PIECE;
-      ISL_FOR8(ISL_LOAD_B)
-    }
-    if (nT > 2) {
-      const size_t poff = 2 * PIECE;
-      ISL_FOR8(ISL_LOAD_C)
-    }
-    for (uint32_t t = 0; t < nT; t += 3) {
-      ISL_FOR8(ISL_STORE_A)
+    consume(t);
+    __syncthreads();
+    if (prof3 && t == 0) { uint64_t n_ = __builtin_amdgcn_s_memrealtime(); prof3[1] += n_ - tw0; tw0 = n_; }
+    if (t + 1 < nT) {
+      ISL_FOR8(ISL_STORE_B)
       __syncthreads();
-      if (prof3 && t == 0) { uint64_t n_ = __builtin_amdgcn_s_memrealtime(); prof3[0] += n_ - tw0; tw0 = n_; }
-      if (t + 3 < nT) {
-        const size_t poff = (size_t)(t + 3) * PIECE;
-        ISL_FOR8(ISL_LOAD_A)
+      if (t + 4 < nT) {
+        const size_t poff = (size_t)(t + 4) * PIECE;
+        ISL_FOR8(ISL_LOAD_B)
       }
-      consume(t);
+      consume(t + 1);
       __syncthreads();
-      if (prof3 && t == 0) { uint64_t n_ = __builtin_amdgcn_s_memrealtime(); prof3[1] += n_ - tw0; tw0 = n_; }
-      if (t + 1 < nT) {
-        ISL_FOR8(ISL_STORE_B)
-        __syncthreads();
-        if (t + 4 < nT) {
-          const size_t poff = (size_t)(t + 4) * PIECE;
-          ISL_FOR8(ISL_LOAD_B)
-        }
-        consume(t + 1);
-        __syncthreads();
-      }
-      if (t + 2 < nT) {
-        ISL_FOR8(ISL_STORE_C)
-        __syncthreads();
-        if (t + 5 < nT) {
-          const size_t poff = (size_t)(t + 5) * PIECE;
-          ISL_FOR8(ISL_LOAD_C)
-        }
-        consume(t + 2);
-        __syncthreads();
-      }
     }
-    if (METRIC == METRIC_COSINE_PRE) a1 = __shfl(row_aux, (int)((g0 + lane) & 63));
-    float dist = dfinish<METRIC>(a0, a1, q_norm);
-    // lane j of this group computed row g0 + j: hand the value to lane g0 + j
-    float moved = __shfl(dist, (lane - (int)g0) & 63);
-    if ((uint32_t)lane >= g0 && (uint32_t)lane < g0 + Rg) result = moved;
+    if (t + 2 < nT) {
+      ISL_FOR8(ISL_STORE_C)
+      __syncthreads();
+      if (t + 5 < nT) {
+        const size_t poff = (size_t)(t + 5) * PIECE;
+        ISL_FOR8(ISL_LOAD_C)
+      }
+      consume(t + 2);
+      __syncthreads();
+    }
+  }
+#undef ISL_FOR8
 #undef ISL_DECL
 #undef ISL_LOAD_A
 #undef ISL_LOAD_B
@@ -218,8 +217,30 @@ __device__ __forceinline__ float wave_distances(const float* __restrict__ emb, u
 #undef ISL_STORE_A
 #undef ISL_STORE_B
 #undef ISL_STORE_C
+  if (METRIC == METRIC_COSINE_PRE) a1 = __shfl(row_aux, (int)((g0 + lane) & 63));
+  return dfinish<METRIC>(a0, a1, q_norm);
+}
+
+// Distances of R (<= 64) rows to the query held in LDS (`qs`); lane r < R owns row `rid` and
+// returns its distance.  Rows are handled in groups of GROUP = 16 (see group_distances).
+template <int METRIC>
+__device__ __forceinline__ float wave_distances(const float* __restrict__ emb, uint64_t stride,
+                                                uint32_t d, uint32_t rid, uint32_t R,
+                                                const float* qs, float* tile, float q_norm,
+                                                float row_aux = 0.0f, uint64_t* prof3 = nullptr) {
+  const int lane = threadIdx.x;
+  float result = 0.0f;
+  for (uint32_t g0 = 0; g0 < R; g0 += GROUP) {
+    const uint32_t Rg = R - g0 < (uint32_t)GROUP ? R - g0 : (uint32_t)GROUP;
+    float dist;
+    if (Rg <= 2) dist = group_distances<METRIC, 1>(emb, stride, d, rid, g0, Rg, qs, tile, q_norm, row_aux, prof3);
+    else if (Rg <= 4) dist = group_distances<METRIC, 2>(emb, stride, d, rid, g0, Rg, qs, tile, q_norm, row_aux, prof3);
+    else if (Rg <= 8) dist = group_distances<METRIC, 4>(emb, stride, d, rid, g0, Rg, qs, tile, q_norm, row_aux, prof3);
+    else dist = group_distances<METRIC, 8>(emb, stride, d, rid, g0, Rg, qs, tile, q_norm, row_aux, prof3);
+    // lane j of this group computed row g0 + j: hand the value to lane g0 + j
+    float moved = __shfl(dist, (lane - (int)g0) & 63);
+    if ((uint32_t)lane >= g0 && (uint32_t)lane < g0 + Rg) result = moved;
   }
-#undef ISL_FOR8
   return result;
 }
 

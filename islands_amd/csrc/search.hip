@@ -26,7 +26,6 @@
 #include "device_common.cuh"
 
 #include <algorithm>
-#include <map>
 
 namespace {
 
@@ -145,8 +144,8 @@ struct RSet {
     }
 #pragma unroll
     for (int s = S - 1; s >= 0; --s) {
-      float ud = __shfl_up(d[s], 1);
-      uint32_t ui = __shfl_up(id[s], 1);
+      float ud = shr1_f(d[s]);
+      uint32_t ui = shr1_u(id[s]);
       if (s > 0) {
         float pd = rl_f(d[s - 1], 63);
         uint32_t pi = rl_u(id[s - 1], 63);
@@ -537,13 +536,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       if (p.prof) {
         p.prof[qi * 8 + 0] = tp0; p.prof[qi * 8 + 1] = tp1; p.prof[qi * 8 + 2] = tp2; p.prof[qi * 8 + 3] = tp3;
         p.prof[qi * 8 + 4] = ngroups; p.prof[qi * 8 + 5] = nhops_rows;
-        {
-          uint32_t hwid = 0, xcc = 0;
-          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-          p.prof[qi * 8 + 2] = ((uint64_t)(xcc & 0xf) << 32) | hwid;
-        }
-        p.prof[qi * 8 + 6] = tw[0]; p.prof[qi * 8 + 7] = tw[1]; p.prof[qi * 8 + 3] = tw[2];
+        p.prof[qi * 8 + 6] = tw[0]; p.prof[qi * 8 + 7] = tw[1];
       }
       if (status == QS_REDO) {
         p.redo[atomicAdd(&p.ticket[1], 1u)] = qi;
@@ -1058,28 +1051,8 @@ isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws) {
       grp += pr[i * 8 + 4];
       hr += pr[i * 8 + 5];
     }
-    {
-      std::map<uint64_t, int> per_simd, per_cu;
-      for (uint64_t i = 0; i < nq; i++) {
-        uint64_t v = pr[i * 8 + 2];
-        uint32_t hw = (uint32_t)v, xcc = (uint32_t)(v >> 32);
-        uint32_t simd = (hw >> 4) & 3, cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
-        uint64_t cukey = ((uint64_t)xcc << 16) | (se << 8) | (sh << 4) | cu;
-        per_cu[cukey]++;
-        per_simd[(cukey << 2) | simd]++;
-      }
-      int hist_cu[16] = {0}, hist_simd[16] = {0};
-      for (auto& kv : per_cu) hist_cu[std::min(kv.second, 15)]++;
-      for (auto& kv : per_simd) hist_simd[std::min(kv.second, 15)]++;
-      fprintf(stderr, "[isl] waves per CU histogram (1..8):");
-      for (int i = 1; i <= 8; i++) fprintf(stderr, " %d", hist_cu[i]);
-      fprintf(stderr, " over %zu CUs; waves per SIMD histogram (1..4):", per_cu.size());
-      for (int i = 1; i <= 4; i++) fprintf(stderr, " %d", hist_simd[i]);
-      fprintf(stderr, "\n");
-    }
-    double w0 = 0, w1 = 0, cyc = 0;
-    for (uint64_t i = 0; i < nq; i++) { w0 += pr[i * 8 + 6] / 100.0; w1 += pr[i * 8 + 7] / 100.0; cyc += pr[i * 8 + 3]; }
-    fprintf(stderr, "[isl] consume of one piece: %.0f shader cycles -> clock %.0f MHz\n", cyc / grp, cyc / w1);
+    double w0 = 0, w1 = 0;
+    for (uint64_t i = 0; i < nq; i++) { w0 += pr[i * 8 + 6] / 100.0; w1 += pr[i * 8 + 7] / 100.0; }
     fprintf(stderr, "[isl] per query: %.1f hops with new rows, %.1f row groups of <=16; per group: first piece "
             "landed+stored after %.2f us, one piece consumed in %.2f us\n", hr / nq, grp / nq, w0 / grp, w1 / grp);
     fprintf(stderr, "[isl] mean us per query by phase: select+adjacency %.0f, visited %.0f, rows+distance %.0f, "
