@@ -551,6 +551,10 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
   }
 }
 
+}  // namespace
+#include "search_quad.cuh"
+namespace {
+
 // ----------------------------------------------------------------- exact kernel
 template <int METRIC_API>
 __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
@@ -784,6 +788,16 @@ void launch_fast(int metric, uint32_t grid, size_t lds, hipStream_t st, const Se
   }
 }
 
+template <int NS>
+void launch_quad(int metric, uint32_t grid, size_t lds, hipStream_t st, const SearchParams& p) {
+  switch (metric) {
+    case ISL_METRIC_COSINE: launch_one(leann_search_quad<NS, ISL_METRIC_COSINE>, grid, lds, st, p); break;
+    case ISL_METRIC_EUCLIDEAN: launch_one(leann_search_quad<NS, ISL_METRIC_EUCLIDEAN>, grid, lds, st, p); break;
+    case ISL_METRIC_DOT: launch_one(leann_search_quad<NS, ISL_METRIC_DOT>, grid, lds, st, p); break;
+    default: launch_one(leann_search_quad<NS, ISL_METRIC_MANHATTAN>, grid, lds, st, p); break;
+  }
+}
+
 void launch_exact(int metric, uint32_t grid, size_t lds, hipStream_t st, const SearchParams& p) {
   switch (metric) {
     case ISL_METRIC_COSINE: launch_one(leann_search_exact<ISL_METRIC_COSINE>, grid, lds, st, p); break;
@@ -921,6 +935,21 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   uint32_t per_cu = (uint32_t)std::min<size_t>(8, (160 * 1024) / fg.lds);
   if (per_cu == 0) use_fast = false;
   uint32_t slots = std::max<uint32_t>(1, (uint32_t)ncu * std::max<uint32_t>(per_cu, 1));
+  // four queries per wave (search_quad.cuh) whenever the result set fits 8 slots x 16 lanes
+  uint32_t quad_hbits = ef <= 64 ? 10 : 11;
+  if (const char* hb = getenv("ISL_QUAD_HBITS")) quad_hbits = (uint32_t)atoi(hb);
+  const size_t quad_lds = ((size_t)16 << quad_hbits) + (size_t)QTILE_ROWS * QTILE_LD * 4 + 256 + 1024 +
+                          (size_t)4 * (((d + 3) / 4 * 4) + 16) * 4;
+  // Experimental (ISL_QUAD=1): correct (same parity tests) but 3.4x slower than the one-query
+  // kernel in round 1 -- only 2 waves per CU fit (four 8-KiB visited tables per wave) and a
+  // lockstep step costs 35 us; see DESIGN.md section 4.
+  bool use_quad = use_fast && ef <= 128 && quad_lds <= 160 * 1024 && getenv("ISL_QUAD");
+  uint32_t quad_per_cu = use_quad ? (uint32_t)std::min<size_t>(4, (160 * 1024) / quad_lds) : 0;
+  uint32_t quad_grid = 0;
+  if (use_quad) {
+    quad_grid = (uint32_t)std::min<uint64_t>((nq + 3) / 4, (uint64_t)ncu * quad_per_cu);
+    slots = std::max<uint32_t>(slots, quad_grid * 4);
+  }
   const uint32_t plog_cap = std::max<uint32_t>(1024, 12 * ef);  // pushes per query ~ 3-6 x ef
   ISL_TRY(prepare_workspace(ws, (uint32_t)nq, slots, plog_cap));
   ISL_TRY(prepare_exact(idx, ws));
@@ -976,7 +1005,17 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
 
   ISL_HIP(hipMemsetAsync(ws.ticket, 0, 64, st));
   ISL_HIP(hipEventRecord(ws.ev0, st));
-  if (use_fast) {
+  if (use_quad) {
+    SearchParams pq = p;
+    pq.hbits = quad_hbits;
+    const int metric = (int)idx->cfg.metric;
+    if (ef <= 32) launch_quad<2>(metric, quad_grid, quad_lds, st, pq);
+    else launch_quad<8>(metric, quad_grid, quad_lds, st, pq);
+    ISL_HIP(hipGetLastError());
+    size_t rlds = (size_t)(ef + 1) * 8 + 16 + 64 * 8 + 16;
+    launch_one(leann_replay_order, 64, rlds, st, pq);
+    ISL_HIP(hipGetLastError());
+  } else if (use_fast) {
     uint32_t grid = (uint32_t)std::min<uint64_t>(nq, slots);
     int S = ef <= 64 ? 1 : ef <= 128 ? 2 : ef <= 256 ? 4 : 8;
     const int metric = (int)idx->cfg.metric;
