@@ -240,6 +240,34 @@ isl_status isl_pq_asymmetric_distance(const isl_pq* pq, const float* query, uint
 isl_status isl_pq_encode(const isl_pq* pq, const float* vectors, uint64_t n, uint64_t d,
                          uint16_t* codes, int32_t mem, void* stream);
 
+/* ---- embedding/candle_provider.rs:434-488: masked mean-pool + optional L2 normalise ----
+ * hidden [B][L][H] f32, mask [B][L] (0/1 as f32), out [B][H].  The BERT forward that
+ * produces `hidden` is third-party code (candle-transformers) and out of this round. */
+isl_status isl_mean_pool_normalize(const float* hidden, const float* mask, uint64_t B, uint64_t L,
+                                   uint64_t H, int32_t normalize, float* out, int32_t mem,
+                                   int32_t device, void* stream);
+
+/* ---- HnswGraph, src/core/hnsw.rs:149-515 (search side) ---- */
+typedef struct isl_hnsw isl_hnsw;
+/* Builds a device-resident HnswGraph from its parts: `levels[i]` = node i's top layer;
+ * layer L adjacency in CSR form over ALL nodes (rows of nodes below layer L are empty):
+ * layer_offsets[L] has num_nodes + 1 entries, layer_neighbors[L] the ids.  vectors: num_nodes
+ * rows of d floats (HnswNode::vector).  m/m0/ef_construction are carried for completeness. */
+isl_status isl_hnsw_from_layers(uint64_t m, uint64_t m0, uint64_t ef_construction, int32_t metric,
+                                uint64_t num_nodes, uint64_t d, uint64_t num_layers,
+                                const uint64_t* const* layer_offsets,
+                                const uint64_t* const* layer_neighbors, const uint64_t* levels,
+                                int32_t has_entry, uint64_t entry_point, uint64_t max_level,
+                                const float* vectors, int32_t device, isl_hnsw** out);
+void isl_hnsw_free(isl_hnsw* h);
+uint64_t isl_hnsw_len(const isl_hnsw* h);
+/* HnswGraph::search (hnsw.rs:458-504) for a batch of queries: greedy descent through layers
+ * max_level..1, then search_layer on layer 0 with ef = max(ef, k); heap order on distance only
+ * (hnsw.rs:136-141), reproduced with an exact BinaryHeap emulation. */
+isl_status isl_hnsw_search_batch(const isl_hnsw* h, const float* queries, uint64_t nq, uint64_t d,
+                                 uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dist,
+                                 uint32_t* out_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,8 @@ __all__ = [
     "CoreError", "DistanceMetric", "PruningStrategy", "LeannConfig", "CsrGraph",
     "InMemoryEmbeddingProvider", "LeannIndex", "ProductQuantizer", "SearchResult",
     "batch_calculate", "calculate", "calculate_squared", "normalize_rows", "merge_topk",
-    "device_count",
+    "device_count", "HnswGraph", "SearchConfig", "Searcher", "MultiIndexSearcher",
+    "mean_pool_normalize",
 ]
 
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -225,6 +226,9 @@ class SearchResult:
     """search.rs:54-103"""
     id: int
     score: float
+    vector: np.ndarray | None = None
+    metadata: object | None = None
+    text: str | None = None
 
     def to_similarity(self) -> float:
         return float(np.float32(1.0) / (np.float32(1.0) + np.float32(self.score)))
@@ -508,3 +512,216 @@ class ProductQuantizer:
         codes = np.zeros((n, self.m), dtype=np.uint16)
         _check(_ffi.lib().isl_pq_encode(self._h, _ptr(v), n, d, _ptr(codes), MEM_HOST, None))
         return codes[0] if single else codes
+
+
+# ------------------------------------------------------------------- hnsw.rs
+class HnswGraph:
+    """Search side of HnswGraph (hnsw.rs:149-515) on the device.  Construction (insert,
+    hnsw.rs:214-329) is outside the search path: the graph is handed over as per-layer adjacency
+    (`layers[L][node]` = neighbour ids of `node` on layer L, empty above the node's level)."""
+
+    def __init__(self, vectors, layers, levels, entry_point: int | None, max_level: int,
+                 m: int = 16, m0: int = 32, ef_construction: int = 200,
+                 metric: DistanceMetric = DistanceMetric.Cosine, device: int = 0):
+        v = _f32(vectors)
+        if v.ndim != 2:
+            v = v.reshape(len(levels), -1) if len(levels) else v.reshape(0, 0)
+        n, d = (v.shape if v.size else (0, 0))
+        self.vectors, self.m, self.m0 = v, m, m0
+        self.ef_construction, self.metric = ef_construction, DistanceMetric(metric)
+        offs, adjs = [], []
+        for L in range(len(layers)):
+            lens = np.fromiter((len(layers[L][i]) for i in range(n)), dtype=np.uint64, count=n)
+            off = np.zeros(n + 1, dtype=np.uint64)
+            np.cumsum(lens, out=off[1:])
+            flat = [x for i in range(n) for x in layers[L][i]]
+            adj = np.asarray(flat if flat else [0], dtype=np.uint64)
+            offs.append(off)
+            adjs.append(adj)
+        self._keep = (offs, adjs)
+        nl = len(layers)
+        poff = (C.c_void_p * max(nl, 1))(*[o.ctypes.data for o in offs])
+        padj = (C.c_void_p * max(nl, 1))(*[a.ctypes.data for a in adjs])
+        lv = np.ascontiguousarray(levels, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(_ffi.lib().isl_hnsw_from_layers(
+            m, m0, ef_construction, int(metric), n, d, nl, poff, padj,
+            _ptr(lv) if n else None, 0 if entry_point is None else 1, entry_point or 0,
+            max_level, _ptr(v) if n else None, device, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                _ffi.lib().isl_hnsw_free(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    def __len__(self) -> int:
+        return int(_ffi.lib().isl_hnsw_len(self._h))
+
+    def len(self) -> int:
+        return len(self)
+
+    def is_empty(self) -> bool:
+        return len(self) == 0
+
+    def get_vector(self, node: int):
+        """get_node(id).vector, hnsw.rs:507-510"""
+        return self.vectors[node] if 0 <= node < self.vectors.shape[0] else None
+
+    def search_batch(self, queries, k: int, ef: int):
+        """Batched HnswGraph::search (hnsw.rs:458-504): per query the (id, distance) list."""
+        q = _f32(queries)
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        nq, d = q.shape
+        ids = np.zeros((nq, max(k, 1)), dtype=np.uint64)
+        dd = np.zeros((nq, max(k, 1)), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        _check(_ffi.lib().isl_hnsw_search_batch(self._h, _ptr(q), nq, d, k, ef, _ptr(ids),
+                                                _ptr(dd), _ptr(cnt)))
+        return [(ids[i, :cnt[i]].copy(), dd[i, :cnt[i]].copy()) for i in range(nq)]
+
+    def search(self, query, k: int, ef: int):
+        ids, dd = self.search_batch(query, k, ef)[0]
+        return [(int(i), float(s)) for i, s in zip(ids, dd)]
+
+
+# ----------------------------------------------------------------- search.rs
+@dataclass
+class SearchConfig:
+    """SearchConfig, search.rs:8-52"""
+    top_k: int = 10
+    ef: int = 100
+    include_vectors: bool = False
+    include_metadata: bool = True
+    min_similarity: float | None = None
+
+    @classmethod
+    def fast(cls, k: int) -> "SearchConfig":
+        return cls(top_k=k, ef=k * 2)
+
+    @classmethod
+    def accurate(cls, k: int) -> "SearchConfig":
+        return cls(top_k=k, ef=k * 10)
+
+
+def _to_results(graph, ids, dd, cfg: SearchConfig):
+    out = []
+    for i, s in zip(ids, dd):
+        r = SearchResult(int(i), float(s))
+        if cfg.include_vectors:
+            vec = graph.get_vector(int(i))
+            if vec is not None:
+                r.vector = vec.copy()
+        out.append(r)
+    return out
+
+
+class Searcher:
+    """Searcher, search.rs:105-182.  `search_batch` is one device launch instead of the
+    reference's sequential map (search.rs:179-181)."""
+
+    def __init__(self, graph: HnswGraph, config: SearchConfig | None = None):
+        self.graph = graph
+        self.config = config or SearchConfig()
+
+    @classmethod
+    def with_config(cls, graph: HnswGraph, config: SearchConfig) -> "Searcher":
+        return cls(graph, config)
+
+    def top_k(self, k: int) -> "Searcher":
+        self.config.top_k = k
+        return self
+
+    def ef(self, ef: int) -> "Searcher":
+        self.config.ef = ef
+        return self
+
+    def include_vectors(self) -> "Searcher":
+        self.config.include_vectors = True
+        return self
+
+    def min_similarity(self, threshold: float) -> "Searcher":
+        self.config.min_similarity = threshold
+        return self
+
+    def search_batch(self, queries):
+        cfg = self.config
+        out = []
+        for ids, dd in self.graph.search_batch(queries, cfg.top_k, cfg.ef):
+            res = _to_results(self.graph, ids, dd, cfg)
+            if cfg.min_similarity is not None:  # retain(to_similarity() >= min_sim), f32
+                thr = np.float32(cfg.min_similarity)
+                res = [r for r in res
+                       if np.float32(1.0) / (np.float32(1.0) + np.float32(r.score)) >= thr]
+            out.append(res)
+        return out
+
+    def search(self, query):
+        return self.search_batch(_f32(query).reshape(1, -1))[0]
+
+
+class MultiIndexSearcher:
+    """MultiIndexSearcher, search.rs:184-256: every index answers the query, the lists are
+    concatenated in insertion order, stable-sorted by score and truncated (isl_merge_topk)."""
+
+    def __init__(self, config: SearchConfig | None = None, device: int = 0):
+        self.graphs: list[tuple[str, HnswGraph]] = []
+        self.config = config or SearchConfig()
+        self.device = device
+
+    def add_index(self, name: str, graph: HnswGraph) -> None:
+        self.graphs.append((name, graph))
+
+    def with_config(self, config: SearchConfig) -> "MultiIndexSearcher":
+        self.config = config
+        return self
+
+    def num_indexes(self) -> int:
+        return len(self.graphs)
+
+    def total_vectors(self) -> int:
+        return sum(len(g) for _, g in self.graphs)
+
+    def search_batch(self, queries):
+        cfg = self.config
+        q = _f32(queries)
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        nq, k, nl = q.shape[0], cfg.top_k, len(self.graphs)
+        if nl == 0:
+            return [[] for _ in range(nq)]
+        ids = np.zeros((nl, nq, max(k, 1)), dtype=np.uint64)
+        sc = np.zeros((nl, nq, max(k, 1)), dtype=np.float32)
+        cnt = np.zeros((nl, nq), dtype=np.uint32)
+        for li, (_, g) in enumerate(self.graphs):
+            for qi, (a, b) in enumerate(g.search_batch(q, k, cfg.ef)):
+                ids[li, qi, :len(a)], sc[li, qi, :len(a)], cnt[li, qi] = a, b, len(a)
+        mi, ms, src, mc = merge_topk(ids, sc, cnt, k, device=self.device)
+        out = []
+        for qi in range(nq):
+            row = []
+            for j in range(int(mc[qi])):
+                name, g = self.graphs[int(src[qi, j])]
+                row.append((name, _to_results(g, [mi[qi, j]], [ms[qi, j]], cfg)[0]))
+            out.append(row)
+        return out
+
+    def search(self, query):
+        return self.search_batch(_f32(query).reshape(1, -1))[0]
+
+
+# ------------------------------------------- embedding/candle_provider.rs
+def mean_pool_normalize(hidden, mask, normalize: bool = True, device: int = 0) -> np.ndarray:
+    """Masked mean pooling + optional L2 normalisation of encoder outputs
+    (src/core/embedding/candle_provider.rs:434-488: sum(h * mask) / clamp(sum(mask), 1e-9), then
+    x / sqrt(sum(x^2))).  hidden [B, L, H], mask [B, L] -> [B, H]."""
+    h, mk = _f32(hidden), _f32(mask)
+    B, L, H = h.shape
+    out = np.zeros((B, H), dtype=np.float32)
+    _check(_ffi.lib().isl_mean_pool_normalize(_ptr(h), _ptr(mk), B, L, H, int(normalize),
+                                              _ptr(out), MEM_HOST, device, None))
+    return out

@@ -82,6 +82,14 @@ SIGNATURES = {
     "isl_merge_topk": (i32, [u64, u64, u64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u64,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, i32, i32,
                              C.c_void_p]),
+    "isl_mean_pool_normalize": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, i32, C.c_void_p, i32,
+                                      i32, C.c_void_p]),
+    "isl_hnsw_from_layers": (i32, [u64, u64, u64, i32, u64, u64, u64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, i32, u64, u64, C.c_void_p, i32, P(C.c_void_p)]),
+    "isl_hnsw_free": (None, [C.c_void_p]),
+    "isl_hnsw_len": (u64, [C.c_void_p]),
+    "isl_hnsw_search_batch": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
     "isl_pq_new": (i32, [u64, u64, u64, C.c_void_p, i32, i32, P(C.c_void_p)]),
     "isl_pq_free": (None, [C.c_void_p]),
     "isl_pq_build_distance_tables": (i32, [C.c_void_p, C.c_void_p, u64, u64, C.c_void_p, i32,

@@ -246,6 +246,9 @@ void isl_index_free(isl_index* idx) {
     if (idx->d_adj) (void)hipFree(idx->d_adj);
     if (idx->d_emb) (void)hipFree(idx->d_emb);
     if (idx->d_norm2) (void)hipFree(idx->d_norm2);
+    for (void* q : idx->hnsw_owned) (void)hipFree(q);
+    if (idx->d_layer_off) (void)hipFree((void*)idx->d_layer_off);
+    if (idx->d_layer_adj) (void)hipFree((void*)idx->d_layer_adj);
     for (auto& w : idx->ws) free_workspace(w);
   }
   delete idx;

@@ -119,6 +119,13 @@ struct isl_index {
   float* d_norm2 = nullptr;  // [nvec] sum of squares of every row, reference summation order
   uint64_t nvec = 0, emb_d = 0, emb_stride = 0;
 
+  // HnswGraph facade (hnsw.rs): distance-only heap order + upper layers for the greedy descent
+  bool is_hnsw = false;
+  uint64_t hnsw_layers = 0;
+  const uint64_t** d_layer_off = nullptr;  // device array of device pointers, [max_level + 1]
+  const uint32_t** d_layer_adj = nullptr;
+  std::vector<void*> hnsw_owned;           // device allocations of the upper layers
+
   mutable std::mutex mu;  // serialises searches that share the workspace
   mutable isl::SearchWorkspace ws[isl::kSearchLanes];
   mutable uint64_t next_token = 1;

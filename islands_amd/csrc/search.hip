@@ -26,6 +26,7 @@
 #include "device_common.cuh"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -83,6 +84,10 @@ struct SearchParams {
   uint64_t vis_words;
   uint32_t* ulist;
   uint32_t ulist_cap;
+  // HnswGraph facade (hnsw.rs): adjacency of the layers above 0 for the greedy descent
+  const uint64_t* const* layer_off;  // [max_level + 1] device pointers (index 0 unused)
+  const uint32_t* const* layer_adj;
+  uint32_t max_level;
 };
 
 // ------------------------------------------------------------- sorted result set
@@ -170,6 +175,13 @@ struct CandOrder {  // Reverse<(OrderedFloat<f32>, u64)>, leann.rs:907
   __device__ static bool le(float ad, uint32_t ai, float bd, uint32_t bi) {
     return ResultOrder::le(bd, bi, ad, ai);
   }
+};
+
+struct HnswCandOrder {  // hnsw.rs:136-141: Candidate::cmp = other.distance.cmp(self.distance)
+  __device__ static bool le(float ad, uint32_t, float bd, uint32_t) { return ordkey(bd) <= ordkey(ad); }
+};
+struct HnswResultOrder {  // Reverse<Candidate>, hnsw.rs:349
+  __device__ static bool le(float ad, uint32_t, float bd, uint32_t) { return ordkey(ad) <= ordkey(bd); }
 };
 
 template <class ORD>
@@ -556,9 +568,13 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
 namespace {
 
 // ----------------------------------------------------------------- exact kernel
-template <int METRIC_API>
+// HNSW = true: HnswGraph::search (hnsw.rs:458-504): greedy descent through the upper layers,
+// then the same layer-0 loop with heaps ordered on distance only (hnsw.rs:136-141, 332-402).
+template <int METRIC_API, bool HNSW>
 __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
   constexpr int METRIC = METRIC_API == ISL_METRIC_COSINE ? METRIC_COSINE_PRE : METRIC_API;
+  using CandOrd = typename std::conditional<HNSW, HnswCandOrder, CandOrder>::type;
+  using ResOrd = typename std::conditional<HNSW, HnswResultOrder, ResultOrder>::type;
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
   const uint32_t ef = p.ef;
@@ -597,14 +613,51 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
       status = QS_NODE_NOT_FOUND;
       payload = p.entry;
     } else {
-      float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[p.entry] : 0.0f;
-      float ed = wave_distances<METRIC>(p.emb, p.stride, p.d, p.entry, 1, qs, tile, q_norm, e_aux);
+      uint32_t entry = p.entry;
+      float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[entry] : 0.0f;
+      float ed = rl_f(wave_distances<METRIC>(p.emb, p.stride, p.d, entry, 1, qs, tile, q_norm, e_aux), 0);
       cV = 1;
-      if (lane == 0) {
-        vis[p.entry >> 5] |= 1u << (p.entry & 31);
-        heap_push<CandOrder>(cand_d, cand_i, clen, ed, p.entry);
+      if (HNSW) {
+        // greedy search from the top layer down to layer 1, hnsw.rs:478-497: per round the
+        // neighbours of the node the round STARTED at are scanned in order, `current` moves to
+        // every strictly closer one (= first occurrence of the minimum if it beats current)
+        for (uint32_t layer = p.max_level; layer >= 1 && status == QS_OK; --layer) {
+          const uint64_t* loff = p.layer_off[layer];
+          const uint32_t* ladj = p.layer_adj[layer];
+          for (;;) {
+            const uint64_t o0 = loff[entry], o1 = loff[entry + 1];
+            const uint32_t deg = (uint32_t)(o1 - o0);
+            bool changed = false;
+            uint32_t cur = entry;
+            float cur_d = ed;
+            for (uint32_t base = 0; base < deg && status == QS_OK; base += 64) {
+              const uint32_t R = deg - base < 64 ? deg - base : 64;
+              const uint32_t nid = (uint32_t)lane < R ? ladj[o0 + base + lane] : 0u;
+              const uint64_t bad = ballot((uint32_t)lane < R && (uint64_t)nid >= p.nvec);
+              if (bad) {  // HnswGraph::distance -> NodeNotFound, hnsw.rs:449-455
+                status = QS_NODE_NOT_FOUND;
+                payload = rl_u(nid, __ffsll((long long)bad) - 1);
+                break;
+              }
+              float r_aux = (METRIC == METRIC_COSINE_PRE && (uint32_t)lane < R) ? p.norm2[nid] : 0.0f;
+              float nd = wave_distances<METRIC>(p.emb, p.stride, p.d, nid, R, qs, tile, q_norm, r_aux);
+              cV += R;
+              for (uint32_t r = 0; r < R; ++r) {  // in list order, strict `<` (hnsw.rs:485)
+                float dr = rl_f(nd, (int)r);
+                if (dr < cur_d) { cur = rl_u(nid, (int)r); cur_d = dr; changed = true; }
+              }
+            }
+            entry = cur;
+            ed = cur_d;
+            if (!changed || status != QS_OK) break;
+          }
+        }
+      }
+      if (lane == 0 && status == QS_OK) {
+        vis[entry >> 5] |= 1u << (entry & 31);
+        heap_push<CandOrd>(cand_d, cand_i, clen, ed, entry);
         uint64_t rl = rlen;
-        heap_push<ResultOrder>(res_d, res_i, rl, ed, p.entry);
+        heap_push<ResOrd>(res_d, res_i, rl, ed, entry);
         rlen = rl;
       }
       cP = 1;
@@ -618,7 +671,7 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
         uint32_t go = 0, cid = 0;
         if (clen > 0) {
           float cd;
-          heap_pop<CandOrder>(cand_d, cand_i, clen, cd, cid);
+          heap_pop<CandOrd>(cand_d, cand_i, clen, cd, cid);
           go = 1;
           if (rlen > 0 && rlen >= ef && ordkey(cd) > ordkey(res_d[0])) go = 0;
         }
@@ -693,13 +746,13 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
             bool should_add = rlen < ef || rlen == 0 || d < res_d[0];
             if (should_add) {
               if (clen >= p.cand_cap) { st = QS_SCRATCH; break; }
-              heap_push<CandOrder>(cand_d, cand_i, clen, d, id);
-              heap_push<ResultOrder>(res_d, res_i, rlen, d, id);
+              heap_push<CandOrd>(cand_d, cand_i, clen, d, id);
+              heap_push<ResOrd>(res_d, res_i, rlen, d, id);
               pushes++;
               if (rlen > ef) {
                 float dd;
                 uint32_t di;
-                heap_pop<ResultOrder>(res_d, res_i, rlen, dd, di);
+                heap_pop<ResOrd>(res_d, res_i, rlen, dd, di);
               }
             }
           }
@@ -798,13 +851,19 @@ void launch_quad(int metric, uint32_t grid, size_t lds, hipStream_t st, const Se
   }
 }
 
-void launch_exact(int metric, uint32_t grid, size_t lds, hipStream_t st, const SearchParams& p) {
+template <bool HNSW>
+void launch_exact_t(int metric, uint32_t grid, size_t lds, hipStream_t st, const SearchParams& p) {
   switch (metric) {
-    case ISL_METRIC_COSINE: launch_one(leann_search_exact<ISL_METRIC_COSINE>, grid, lds, st, p); break;
-    case ISL_METRIC_EUCLIDEAN: launch_one(leann_search_exact<ISL_METRIC_EUCLIDEAN>, grid, lds, st, p); break;
-    case ISL_METRIC_DOT: launch_one(leann_search_exact<ISL_METRIC_DOT>, grid, lds, st, p); break;
-    default: launch_one(leann_search_exact<ISL_METRIC_MANHATTAN>, grid, lds, st, p); break;
+    case ISL_METRIC_COSINE: launch_one(leann_search_exact<ISL_METRIC_COSINE, HNSW>, grid, lds, st, p); break;
+    case ISL_METRIC_EUCLIDEAN: launch_one(leann_search_exact<ISL_METRIC_EUCLIDEAN, HNSW>, grid, lds, st, p); break;
+    case ISL_METRIC_DOT: launch_one(leann_search_exact<ISL_METRIC_DOT, HNSW>, grid, lds, st, p); break;
+    default: launch_one(leann_search_exact<ISL_METRIC_MANHATTAN, HNSW>, grid, lds, st, p); break;
   }
+}
+void launch_exact(int metric, bool hnsw, uint32_t grid, size_t lds, hipStream_t st,
+                  const SearchParams& p) {
+  if (hnsw) launch_exact_t<true>(metric, grid, lds, st, p);
+  else launch_exact_t<false>(metric, grid, lds, st, p);
 }
 
 __global__ void fill_u32_kernel(uint32_t* p, uint64_t n, uint32_t v) {
@@ -931,7 +990,7 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   if (hipGetDeviceProperties(&prop, idx->device) == hipSuccess) ncu = prop.multiProcessorCount;
 
   FastGeom fg = fast_geometry(ef, (uint32_t)d);
-  bool use_fast = ef <= 512 && ef >= 1 && idx->max_degree <= 64;
+  bool use_fast = ef <= 512 && ef >= 1 && idx->max_degree <= 64 && !idx->is_hnsw;
   uint32_t per_cu = (uint32_t)std::min<size_t>(8, (160 * 1024) / fg.lds);
   if (per_cu == 0) use_fast = false;
   uint32_t slots = std::max<uint32_t>(1, (uint32_t)ncu * std::max<uint32_t>(per_cu, 1));
@@ -1002,6 +1061,9 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   p.vis_words = ws.vis_words;
   p.ulist = ws.ulist;
   p.ulist_cap = ws.ulist_cap;
+  p.layer_off = idx->d_layer_off;
+  p.layer_adj = idx->d_layer_adj;
+  p.max_level = idx->is_hnsw ? (uint32_t)idx->max_level : 0u;
 
   ISL_HIP(hipMemsetAsync(ws.ticket, 0, 64, st));
   ISL_HIP(hipEventRecord(ws.ev0, st));
@@ -1037,7 +1099,7 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   }
   {
     uint32_t grid = (uint32_t)std::min<uint64_t>(nq, ws.exact_slots);
-    launch_exact((int)idx->cfg.metric, grid, exact_lds(ef, (uint32_t)d), st, p);
+    launch_exact((int)idx->cfg.metric, idx->is_hnsw, grid, exact_lds(ef, (uint32_t)d), st, p);
     ISL_HIP(hipGetLastError());
   }
   ISL_HIP(hipEventRecord(ws.ev1, st));
