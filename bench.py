@@ -24,6 +24,9 @@ import argparse
 import json
 import os
 import sys
+
+# one hardware queue per search lane in flight (the HIP default is 4 queues per process)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import threading
 import time
 
@@ -186,7 +189,7 @@ def main():
         truths.append((ti + lo, td))
     torch.cuda.synchronize()
 
-    depth = max(1, min(args.pipeline, 4))
+    depth = max(1, min(args.pipeline, 8))
     # one output set per search in flight
     outs = [(torch.zeros((nq, k), dtype=torch.int64, device=dev),
              torch.zeros((nq, k), dtype=torch.float32, device=dev),

@@ -1,6 +1,8 @@
 // Device helpers shared by the kernels of libislands_amd.so: wave-level utilities and the
-// exact-order distance routine (one lane owns one row and runs the reference's strictly
-// sequential f32 chain; rows are staged through an LDS tile with coalesced 16-byte loads).
+// exact-order distance routine (the four lanes of a quad own one row: each multiplies four of
+// every 16 elements, all four run the reference's strictly sequential f32 add chain and pull
+// the products out of each other with DPP quad_perm; rows are staged through an LDS tile with
+// coalesced 16-byte loads).
 // Translation units including this file must be built with -ffp-contract=off.
 #pragma once
 
@@ -10,7 +12,9 @@ namespace isl_dev {
 
 constexpr int PIECE = 128;           // floats of one row staged per step (512 B; a wave-instruction
                                      // moves the pieces of two rows)
-constexpr int TILE_LD = PIECE + 4;   // LDS row pitch in floats: 132*r mod 64 = 4r -> conflict-free b128
+constexpr int TILE_LD = PIECE + 16;  // LDS row pitch in floats: lane (row r, quarter s) reads the float4
+                                     // at 144 r + 16 i + 4 s -> bank 16 r + 4 s (mod 64): the 16 lanes
+                                     // of four consecutive rows cover the 64 banks exactly once
 constexpr int GROUP = 16;            // rows staged together
 constexpr int TILE_ROWS = GROUP;
 constexpr int METRIC_SUMSQ = 100;   // internal: sqrt(sum x*x) (normalize_vector, distance.rs:126)
@@ -67,6 +71,13 @@ __device__ __forceinline__ uint32_t prune_keep(float prune_ratio, uint32_t strat
   return num_to_keep < n ? num_to_keep : n;
 }
 
+// value of `v` in lane SEL of the caller's quad (DPP quad_perm:[SEL,SEL,SEL,SEL]; folds into the
+// consuming v_add_f32 as its DPP source operand)
+template <int SEL>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), SEL * 0x55, 0xf, 0xf, true));
+}
+
 // ------------------------------------------------------- exact-order distances
 // One step of the reference's scalar loops (distance.rs:71-122); q = query element
 // (a), x = row element (b).  Separate roundings: this file is built -ffp-contract=off.
@@ -92,6 +103,20 @@ __device__ __forceinline__ void dstep(float q, float x, float& a0, float& a1) {
   }
 }
 
+// The addend one element contributes to the main chain (dstep's `a0 += ...` operand).
+template <int METRIC>
+__device__ __forceinline__ float dterm(float q, float x) {
+  if (METRIC == ISL_METRIC_COSINE || METRIC == ISL_METRIC_DOT || METRIC == METRIC_COSINE_PRE) {
+    return q * x;
+  } else if (METRIC == ISL_METRIC_EUCLIDEAN || METRIC == METRIC_EUCLID_SQ) {
+    float diff = q - x;
+    return diff * diff;
+  } else if (METRIC == METRIC_SUMSQ || METRIC == METRIC_SUMSQ_RAW) {
+    return x * x;
+  }
+  return fabsf(q - x);
+}
+
 template <int METRIC>
 __device__ __forceinline__ float dfinish(float a0, float a1, float q_norm) {
   if (METRIC == ISL_METRIC_COSINE || METRIC == METRIC_COSINE_PRE) {
@@ -111,9 +136,8 @@ __device__ __forceinline__ float dfinish(float a0, float a1, float q_norm) {
 // One group of Rg <= 2*NI rows (NI = load instructions per piece, compile-time).  Every
 // wave-instruction moves one 512-byte piece (PIECE floats) of TWO rows, fully coalesced
 // (32 lanes x 16 B per row); three pieces per row are in flight (register ring A/B/C) while
-// lanes 0..Rg-1 run the sequential chains of the piece that already sits in the LDS tile
-// (GROUP x TILE_LD floats, read back row-per-lane with conflict-free ds_read_b128:
-// 132*r mod 64 = 4r).  All loads and LDS stores of a variant are unconditional straight-line
+// quads 0..Rg-1 run the sequential chains of the piece that already sits in the LDS tile
+// (GROUP x TILE_LD floats, read back with conflict-free ds_read_b128).  All loads and LDS stores of a variant are unconditional straight-line
 // code -- a predicate per instruction makes hipcc fall back to s_waitcnt vmcnt(0) before every
 // store, which serialises the ring; lanes whose row does not exist re-read the group's first
 // row (same cache lines) into a tile row that no lane consumes.
@@ -142,28 +166,54 @@ __device__ __forceinline__ float group_distances(const float* __restrict__ emb, 
 #define ISL_STORE_C(j) \
   if constexpr ((j) < NI) *reinterpret_cast<float4*>(tile + (2 * (j) + half) * TILE_LD + col) = rc##j;
   float a0 = 0.0f, a1 = 0.0f;
+  // The chain of row r runs in all four lanes of quad r (same operands, same order -> same
+  // bits); lane s of the quad owns elements 16i + 4s .. 16i + 4s + 3 of every 16: one
+  // ds_read_b128 of x and of q and four multiplies per 16 elements instead of per 4, the 16
+  // dependent adds take their addend straight from the owning lane (v_add_f32_dpp quad_perm).
+  // The dependent add (about 14.5 cycles on gfx950) is the critical path either way; what this
+  // layout buys is issue slots: 1.25 VALU and 0.125 LDS instructions per element, not 2 and 0.5.
+#define ISL_ADD(ss, c)                                                           \
+  a0 += quad_bcast<ss>(p##c);                                                     \
+  if constexpr (METRIC == ISL_METRIC_COSINE) a1 += quad_bcast<ss>(n##c);
+#define ISL_ADD_G(ss, c) if (j + 4 * (ss) + (c) < cnt) { ISL_ADD(ss, c) }
+#define ISL_QUARTER(A, ss) A(ss, 0) A(ss, 1) A(ss, 2) A(ss, 3)
+#define ISL_TERMS                                                                              \
+  const float p0 = dterm<METRIC>(q.x, x.x), p1 = dterm<METRIC>(q.y, x.y),                      \
+              p2 = dterm<METRIC>(q.z, x.z), p3 = dterm<METRIC>(q.w, x.w);                      \
+  const float n0 = x.x * x.x, n1 = x.y * x.y, n2 = x.z * x.z, n3 = x.w * x.w;                  \
+  (void)n0; (void)n1; (void)n2; (void)n3;
   auto consume = [&](uint32_t t) {
-    if ((uint32_t)lane < Rg) {
-      const float* trow = tile + lane * TILE_LD;
-      // unroll 8 keeps 16 ds_read_b128 in flight: measured sweet spot for one wave
-      // (16.2 cycles/element; unroll 16 -> 26.5, unroll 4 -> 18.9)
-      const float* qv = qs + t * PIECE;
+    if ((uint32_t)(lane >> 2) < Rg) {
+      const uint32_t s4 = (uint32_t)(lane & 3) * 4u;
+      const float* trow = tile + (lane >> 2) * TILE_LD + s4;
+      const float* qv = qs + t * PIECE + s4;
       const uint32_t cnt = d - t * PIECE;
       if (cnt >= (uint32_t)PIECE) {
-#pragma unroll 8
-        for (int j = 0; j < PIECE; j += 4) {
-          float4 x = *reinterpret_cast<const float4*>(trow + j);
-          float4 q = *reinterpret_cast<const float4*>(qv + j);
-          dstep<METRIC>(q.x, x.x, a0, a1);
-          dstep<METRIC>(q.y, x.y, a0, a1);
-          dstep<METRIC>(q.z, x.z, a0, a1);
-          dstep<METRIC>(q.w, x.w, a0, a1);
+#pragma unroll 4
+        for (int j = 0; j < PIECE; j += 16) {
+          const float4 x = *reinterpret_cast<const float4*>(trow + j);
+          const float4 q = *reinterpret_cast<const float4*>(qv + j);
+          ISL_TERMS
+          ISL_QUARTER(ISL_ADD, 0) ISL_QUARTER(ISL_ADD, 1) ISL_QUARTER(ISL_ADD, 2) ISL_QUARTER(ISL_ADD, 3)
         }
       } else {
-        for (uint32_t j = 0; j < cnt; ++j) dstep<METRIC>(qv[j], trow[j], a0, a1);
+        for (uint32_t j = 0; j < cnt; j += 16) {
+          float4 x = make_float4(0.f, 0.f, 0.f, 0.f), q = x;
+          if (j + s4 < cnt) {  // `qs` holds d rounded up to 4 floats
+            x = *reinterpret_cast<const float4*>(trow + j);
+            q = *reinterpret_cast<const float4*>(qv + j);
+          }
+          ISL_TERMS
+          // elements at or past `cnt` (stale tile / query words) are multiplied but never added
+          ISL_QUARTER(ISL_ADD_G, 0) ISL_QUARTER(ISL_ADD_G, 1) ISL_QUARTER(ISL_ADD_G, 2) ISL_QUARTER(ISL_ADD_G, 3)
+        }
       }
     }
   };
+#undef ISL_ADD
+#undef ISL_ADD_G
+#undef ISL_QUARTER
+#undef ISL_TERMS
   uint64_t tw0 = prof3 ? __builtin_amdgcn_s_memrealtime() : 0;
   {
     const size_t poff = 0;
@@ -185,6 +235,7 @@ __device__ __forceinline__ float group_distances(const float* __restrict__ emb, 
       const size_t poff = (size_t)(t + 3) * PIECE;
       ISL_FOR8(ISL_LOAD_A)
     }
+    if (prof3 && t == 0) { uint64_t n_ = __builtin_amdgcn_s_memrealtime(); prof3[2] += n_ - tw0; tw0 = n_; }
     consume(t);
     __syncthreads();
     if (prof3 && t == 0) { uint64_t n_ = __builtin_amdgcn_s_memrealtime(); prof3[1] += n_ - tw0; tw0 = n_; }
@@ -217,7 +268,7 @@ __device__ __forceinline__ float group_distances(const float* __restrict__ emb, 
 #undef ISL_STORE_A
 #undef ISL_STORE_B
 #undef ISL_STORE_C
-  if (METRIC == METRIC_COSINE_PRE) a1 = __shfl(row_aux, (int)((g0 + lane) & 63));
+  if (METRIC == METRIC_COSINE_PRE) a1 = __shfl(row_aux, (int)((g0 + (lane >> 2)) & 63));
   return dfinish<METRIC>(a0, a1, q_norm);
 }
 
@@ -237,8 +288,153 @@ __device__ __forceinline__ float wave_distances(const float* __restrict__ emb, u
     else if (Rg <= 4) dist = group_distances<METRIC, 2>(emb, stride, d, rid, g0, Rg, qs, tile, q_norm, row_aux, prof3);
     else if (Rg <= 8) dist = group_distances<METRIC, 4>(emb, stride, d, rid, g0, Rg, qs, tile, q_norm, row_aux, prof3);
     else dist = group_distances<METRIC, 8>(emb, stride, d, rid, g0, Rg, qs, tile, q_norm, row_aux, prof3);
-    // lane j of this group computed row g0 + j: hand the value to lane g0 + j
-    float moved = __shfl(dist, (lane - (int)g0) & 63);
+    // quad j of this group computed row g0 + j: hand the value to lane g0 + j
+    float moved = __shfl(dist, (4 * (lane - (int)g0)) & 63);
+    if ((uint32_t)lane >= g0 && (uint32_t)lane < g0 + Rg) result = moved;
+  }
+  return result;
+}
+
+// ---------------------------------------------------------- tile-free variant
+// Same quad layout as group_distances, but every lane fetches its own 16 bytes of every 64
+// straight from global memory into a register ring (RING steps of 16 elements in flight per
+// lane): a wave-load touches one 64-byte segment of up to 16 rows, consecutive steps walk each
+// row sequentially (the second half of every 128-byte line is an L2/TCP hit).  No LDS tile, no
+// ds_write, no barrier: the dependent add chain runs uninterrupted and the kernel's LDS
+// footprint shrinks to the visited table plus the query.  Used by the search kernel, where a
+// hop evaluates ~9 rows; the streaming kernels keep the tile (fully coalesced 512-byte pieces).
+constexpr int RING = 12;
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+#define ISL_RING(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11)
+template <int METRIC>
+__device__ __forceinline__ float direct_group(const float* __restrict__ emb, uint64_t stride,
+                                              uint32_t d, uint32_t rid, uint32_t g0, uint32_t Rg,
+                                              const float* qs, float q_norm, float row_aux) {
+  const int lane = threadIdx.x;
+  const uint32_t r = (uint32_t)lane >> 2;
+  const uint32_t s4 = ((uint32_t)lane & 3u) * 4u;
+  const uint32_t row = (uint32_t)__shfl((int)rid, (int)((g0 + (r < Rg ? r : 0u)) & 63u));
+  float a0 = 0.0f, a1 = 0.0f;
+  if (r < Rg) {
+    const float* rp = emb + (uint64_t)row * stride + s4;
+    const float* qp = qs + s4;
+    const uint32_t nF = d >> 4;          // steps whose 16 elements all exist
+    const uint32_t nS = (d + 15u) >> 4;  // steps in total
+#define ISL_ADD(ss, c)                                                           \
+  a0 += quad_bcast<ss>(p##c);                                                     \
+  if constexpr (METRIC == ISL_METRIC_COSINE) a1 += quad_bcast<ss>(n##c);
+#define ISL_ADD_G(ss, c) if (e0 + 4 * (ss) + (c) < d) { ISL_ADD(ss, c) }
+#define ISL_QUARTER(A, ss) A(ss, 0) A(ss, 1) A(ss, 2) A(ss, 3)
+#define ISL_TERMS                                                                              \
+  const float p0 = dterm<METRIC>(q.x, x.x), p1 = dterm<METRIC>(q.y, x.y),                      \
+              p2 = dterm<METRIC>(q.z, x.z), p3 = dterm<METRIC>(q.w, x.w);                      \
+  const float n0 = x.x * x.x, n1 = x.y * x.y, n2 = x.z * x.z, n3 = x.w * x.w;                  \
+  (void)n0; (void)n1; (void)n2; (void)n3;
+#define ISL_DECLX(k) v4f x##k;
+#define ISL_ISSUE(k) x##k = *reinterpret_cast<const v4f*>(rp + 16u * (base + (k)));
+  // The register ring only works if the reload of slot k is issued inside step k (behind the
+  // multiplies that free the slot, ahead of the 16 dependent adds that hide its latency): the
+  // scheduler would otherwise sink every reload to its first use.  sched_barrier pins VMEM and
+  // lets ALU / DS instructions move; the empty asm makes the whole 128-bit register the load's
+  // only user, so the load is not split into four dword loads.
+#define ISL_PIN __builtin_amdgcn_sched_barrier(0x40F);
+#define ISL_TAKE(k)                                                               \
+    v4f xv = x##k;                                                                \
+    asm volatile("" : "+v"(xv));                                                  \
+    const float4 x = make_float4(xv.x, xv.y, xv.z, xv.w);
+  // the query operand of step k + 1 is read from LDS during step k's adds as well
+#define ISL_QNEXT(k)                                                              \
+    {                                                                             \
+      const uint32_t sn_ = base + (k) + 1u < nS ? base + (k) + 1u : nS - 1u;      \
+      qn = *reinterpret_cast<const float4*>(qp + 16u * sn_);                      \
+    }
+#define ISL_STEP_RELOAD(k)                                                        \
+  {                                                                               \
+    ISL_TAKE(k)                                                                   \
+    const float4 q = qn;                                                          \
+    ISL_TERMS                                                                     \
+    ISL_PIN                                                                       \
+    x##k = *reinterpret_cast<const v4f*>(rp + 16u * (base + RING + (k)));         \
+    ISL_QNEXT(k)                                                                  \
+    ISL_PIN                                                                       \
+    ISL_QUARTER(ISL_ADD, 0) ISL_QUARTER(ISL_ADD, 1) ISL_QUARTER(ISL_ADD, 2) ISL_QUARTER(ISL_ADD, 3) \
+  }
+#define ISL_STEP(k)                                                               \
+  {                                                                               \
+    ISL_TAKE(k)                                                                   \
+    const float4 q = qn;                                                          \
+    ISL_TERMS                                                                     \
+    ISL_PIN                                                                       \
+    ISL_QNEXT(k)                                                                  \
+    ISL_PIN                                                                       \
+    ISL_QUARTER(ISL_ADD, 0) ISL_QUARTER(ISL_ADD, 1) ISL_QUARTER(ISL_ADD, 2) ISL_QUARTER(ISL_ADD, 3) \
+  }
+    ISL_RING(ISL_DECLX)
+    uint32_t base = 0;
+    if (nF >= (uint32_t)RING) {
+      ISL_RING(ISL_ISSUE)
+      float4 qn = *reinterpret_cast<const float4*>(qp);
+      ISL_PIN
+      while (base + 2u * RING <= nF) {
+        ISL_RING(ISL_STEP_RELOAD)
+        base += RING;
+      }
+      ISL_RING(ISL_STEP)
+      base += RING;
+    }
+    if (base < nS) {
+      // fewer than RING + 1 steps left (all of them when d < 16 * RING): loads first, clamped to
+      // the last step so that they stay unconditional, then the guarded chains
+      const uint32_t rem = nS - base;
+      const uint32_t last = nS - 1u;
+#define ISL_ISSUE_C(k)                                                              \
+  {                                                                                 \
+    const uint32_t st_ = base + (k) < last ? base + (k) : last;                     \
+    x##k = *reinterpret_cast<const v4f*>(rp + 16u * st_);                           \
+  }
+#define ISL_STEP_G(k)                                                               \
+  if ((uint32_t)(k) < rem) {                                                        \
+    const uint32_t e0 = 16u * (base + (k));                                         \
+    ISL_TAKE(k)                                                                     \
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);                                     \
+    if (e0 + s4 < ((d + 3u) & ~3u)) q = *reinterpret_cast<const float4*>(qp + e0); \
+    ISL_TERMS                                                                       \
+    ISL_QUARTER(ISL_ADD_G, 0) ISL_QUARTER(ISL_ADD_G, 1) ISL_QUARTER(ISL_ADD_G, 2) ISL_QUARTER(ISL_ADD_G, 3) \
+  }
+      ISL_RING(ISL_ISSUE_C)
+      ISL_RING(ISL_STEP_G)
+#undef ISL_ISSUE_C
+#undef ISL_STEP_G
+    }
+#undef ISL_ADD
+#undef ISL_ADD_G
+#undef ISL_QUARTER
+#undef ISL_TERMS
+#undef ISL_DECLX
+#undef ISL_ISSUE
+#undef ISL_PIN
+#undef ISL_TAKE
+#undef ISL_QNEXT
+#undef ISL_STEP_RELOAD
+#undef ISL_STEP
+  }
+  if (METRIC == METRIC_COSINE_PRE) a1 = __shfl(row_aux, (int)((g0 + r) & 63u));
+  return dfinish<METRIC>(a0, a1, q_norm);
+}
+#undef ISL_RING
+
+// Tile-free counterpart of wave_distances: lane j < R receives the distance of row rid(j).
+template <int METRIC>
+__device__ __forceinline__ float direct_distances(const float* __restrict__ emb, uint64_t stride,
+                                                  uint32_t d, uint32_t rid, uint32_t R,
+                                                  const float* qs, float q_norm, float row_aux = 0.0f) {
+  const int lane = threadIdx.x;
+  float result = 0.0f;
+  for (uint32_t g0 = 0; g0 < R; g0 += GROUP) {
+    const uint32_t Rg = R - g0 < (uint32_t)GROUP ? R - g0 : (uint32_t)GROUP;
+    float dist = direct_group<METRIC>(emb, stride, d, rid, g0, Rg, qs, q_norm, row_aux);
+    float moved = __shfl(dist, (4 * (lane - (int)g0)) & 63);
     if ((uint32_t)lane >= g0 && (uint32_t)lane < g0 + Rg) result = moved;
   }
   return result;

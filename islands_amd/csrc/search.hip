@@ -298,8 +298,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
   const uint32_t hmask = hcap - 1;
   const uint32_t hlimit = hcap - hcap / 8;  // load factor 0.875
   uint32_t* htab = reinterpret_cast<uint32_t*>(smem);
-  float* tile = reinterpret_cast<float*>(smem + (size_t)hcap * 4);
-  uint32_t* scratch = reinterpret_cast<uint32_t*>(tile + TILE_ROWS * TILE_LD);
+  uint32_t* scratch = htab + hcap;  // 64 words for the id compaction
   float* qs = reinterpret_cast<float*>(scratch + 64);
   const uint32_t ocap = 1u << p.obits;
   const uint32_t omask = ocap - 1;
@@ -339,7 +338,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       payload = p.entry;
     } else {
       float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[p.entry] : 0.0f;
-      float ed = wave_distances<METRIC>(p.emb, p.stride, p.d, p.entry, 1, qs, tile, q_norm, e_aux);
+      float ed = direct_distances<METRIC>(p.emb, p.stride, p.d, p.entry, 1, qs, q_norm, e_aux);
       ed = rl_f(ed, 0);
       cV = 1;
       if (lane == 0) htab[hslot(p.entry, p.hbits)] = p.entry;
@@ -447,8 +446,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       nhops_rows += 1;
       ISL_MARK(tp1)  // visited set + compaction
       float r_aux = (METRIC == METRIC_COSINE_PRE && (uint32_t)lane < keep) ? p.norm2[uid] : 0.0f;
-      float nd = wave_distances<METRIC>(p.emb, p.stride, p.d, uid, keep, qs, tile, q_norm, r_aux,
-                                        p.prof ? tw : nullptr);
+      float nd = direct_distances<METRIC>(p.emb, p.stride, p.d, uid, keep, qs, q_norm, r_aux);
       ISL_MARK(tp2)  // row fetch + distances
 
       // leann.rs:953-970 in CSR order; worst = results.peek()
@@ -517,9 +515,10 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
     if (status == QS_REPLAY) {
       __threadfence_block();
       __syncthreads();
-      float* res_d = tile;
-      uint32_t* res_i = reinterpret_cast<uint32_t*>(tile + (ef + 1));
-      uint2* stage = reinterpret_cast<uint2*>(tile + 1280);  // 5 KiB into the 8.25 KiB tile
+      // the search is over: the visited table's LDS (>= 4 KiB) becomes the replay's heap + stage
+      float* res_d = reinterpret_cast<float*>(htab);
+      uint32_t* res_i = htab + (ef + 1);
+      uint2* stage = reinterpret_cast<uint2*>(htab + 2 * (ef + 1));
       replay_result_order(plog, cP, ef, p.k, qi, res_d, res_i, stage, p.out_ids, p.out_dist,
                           p.out_count);
       status = QS_OK;
@@ -548,7 +547,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       if (p.prof) {
         p.prof[qi * 8 + 0] = tp0; p.prof[qi * 8 + 1] = tp1; p.prof[qi * 8 + 2] = tp2; p.prof[qi * 8 + 3] = tp3;
         p.prof[qi * 8 + 4] = ngroups; p.prof[qi * 8 + 5] = nhops_rows;
-        p.prof[qi * 8 + 6] = tw[0]; p.prof[qi * 8 + 7] = tw[1];
+        p.prof[qi * 8 + 6] = tw[2]; p.prof[qi * 8 + 7] = tw[1];
       }
       if (status == QS_REDO) {
         p.redo[atomicAdd(&p.ticket[1], 1u)] = qi;
@@ -813,8 +812,8 @@ struct FastGeom {
 FastGeom fast_geometry(uint32_t ef, uint32_t d) {
   // visited capacity grows with ef (V is roughly 10-30 x ef); overflow goes to HBM
   uint32_t hbits = ef <= 64 ? 10 : ef <= 160 ? 11 : ef <= 320 ? 12 : 13;
-  size_t lds = ((size_t)4 << hbits) + (size_t)TILE_ROWS * TILE_LD * 4 + 64 * 4 +
-               (size_t)((d + 3) / 4 * 4) * 4;
+  // query + 64 bytes: the operand prefetch of direct_group may touch one step past the end
+  size_t lds = ((size_t)4 << hbits) + 64 * 4 + (size_t)((d + 3) / 4 * 4) * 4 + 64;
   return {hbits, lds};
 }
 
@@ -991,7 +990,11 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
 
   FastGeom fg = fast_geometry(ef, (uint32_t)d);
   bool use_fast = ef <= 512 && ef >= 1 && idx->max_degree <= 64 && !idx->is_hnsw;
-  uint32_t per_cu = (uint32_t)std::min<size_t>(8, (160 * 1024) / fg.lds);
+  // resident waves per CU: bounded by LDS (visited table + query) and by the kernel's VGPR
+  // budget (<= 128 -> 4 per SIMD)
+  size_t cu_cap = 16;
+  if (const char* wc = getenv("ISL_WAVES_PER_CU")) cu_cap = (size_t)std::max(1, atoi(wc));
+  uint32_t per_cu = (uint32_t)std::min<size_t>(cu_cap, (160 * 1024) / fg.lds);
   if (per_cu == 0) use_fast = false;
   uint32_t slots = std::max<uint32_t>(1, (uint32_t)ncu * std::max<uint32_t>(per_cu, 1));
   // four queries per wave (search_quad.cuh) whenever the result set fits 8 slots x 16 lanes
@@ -1010,7 +1013,8 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
     slots = std::max<uint32_t>(slots, quad_grid * 4);
   }
   const uint32_t plog_cap = std::max<uint32_t>(1024, 12 * ef);  // pushes per query ~ 3-6 x ef
-  ISL_TRY(prepare_workspace(ws, (uint32_t)nq, slots, plog_cap));
+  // per-slot state is indexed by blockIdx.x < min(nq, slots)
+  ISL_TRY(prepare_workspace(ws, (uint32_t)nq, (uint32_t)std::min<uint64_t>(nq + 3, slots), plog_cap));
   ISL_TRY(prepare_exact(idx, ws));
   hipStream_t st = mode == StreamMode::USER ? user_stream : ws.stream;
   if (mode == StreamMode::OWN_AFTER_USER) {
