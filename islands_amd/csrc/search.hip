@@ -91,24 +91,39 @@ struct SearchParams {
 };
 
 // ------------------------------------------------------------- sorted result set
-// R as a sorted array (ascending (OrderedFloat d, id)) of up to 64*S entries; entry e
-// lives in slot e / 64 of lane e % 64.  id bit 31 marks "already expanded".
+// R as a sorted array (ascending (OrderedFloat d, id)) of up to 64*S entries; entry e lives in
+// slot e / 64 of lane e % 64.  Distances are held as their order-preserving integer image
+// (ordkey) so that every comparison is an unsigned compare; the image is invertible because
+// the fast kernel hands queries that meet a NaN or a -0.0 distance to the exact kernel.  id
+// bit 31 marks "already expanded".  Entries at or past `len` hold the all-ones key and id
+// (greater than every real key, and "expanded"), so neither the position count nor the search
+// for the next candidate needs a length test.
+constexpr uint32_t KEY_MAX = 0xFFFFFFFFu;
+
+__device__ __forceinline__ float key_to_dist(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+__device__ __forceinline__ bool odd_distance(float d) {
+  return d != d || __float_as_uint(d) == 0x80000000u;
+}
+
 template <int S>
 struct RSet {
-  float d[S];
+  uint32_t kd[S];
   uint32_t id[S];
   uint32_t len;  // wave-uniform
 
   __device__ void init() {
 #pragma unroll
-    for (int s = 0; s < S; ++s) { d[s] = 0.0f; id[s] = 0u; }
+    for (int s = 0; s < S; ++s) { kd[s] = KEY_MAX; id[s] = KEY_MAX; }
     len = 0;
   }
-  __device__ float dist_at(uint32_t e) const {
-    float r = 0.0f;
+  __device__ uint32_t key_at(uint32_t e) const {
+    uint32_t r = 0;
 #pragma unroll
     for (int s = 0; s < S; ++s)
-      if ((int)(e >> 6) == s) r = rl_f(d[s], e & 63);
+      if ((int)(e >> 6) == s) r = rl_u(kd[s], e & 63);
     return r;
   }
   __device__ uint32_t id_at(uint32_t e) const {
@@ -120,11 +135,9 @@ struct RSet {
   }
   // first entry not yet expanded, or 0xFFFFFFFF
   __device__ uint32_t first_unexpanded() const {
-    const int lane = threadIdx.x;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      uint32_t e = s * 64 + lane;
-      uint64_t m = ballot(e < len && !(id[s] & FLAG_EXP));
+      uint64_t m = ballot(!(id[s] & FLAG_EXP));
       if (m) return s * 64 + (uint32_t)__ffsll((long long)m) - 1;
     }
     return 0xFFFFFFFFu;
@@ -135,34 +148,119 @@ struct RSet {
     for (int s = 0; s < S; ++s)
       if ((int)(e >> 6) == s && lane == (int)(e & 63)) id[s] |= FLAG_EXP;
   }
-  // Inserts (nd, nid) keeping the order; the entry pushed past index cap-1 is lost.
-  __device__ void insert(float nd, uint32_t nid) {
-    const int lane = threadIdx.x;
-    const uint32_t nk = ordkey(nd);
+  // Inserts (nk, nid) keeping the order; entries at index >= cap fall off the end.
+  __device__ __forceinline__ void insert(uint32_t nk, uint32_t nid, uint32_t cap) {
+    const uint32_t lane = threadIdx.x;
     uint32_t pos = 0;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      uint32_t e = s * 64 + lane;
-      uint32_t ek = ordkey(d[s]);
-      bool less = e < len && (ek < nk || (ek == nk && (id[s] & ID_MASK) < nid));
-      pos += (uint32_t)__popcll(ballot(less));
+      const uint64_t lt = ballot(kd[s] < nk);
+      const uint64_t eq = ballot(kd[s] == nk);
+      const uint64_t il = ballot((id[s] & ID_MASK) < nid);
+      pos += (uint32_t)__popcll(lt | (eq & il));
     }
 #pragma unroll
     for (int s = S - 1; s >= 0; --s) {
-      float ud = shr1_f(d[s]);
+      if (pos >= 64u * (uint32_t)(s + 1)) break;  // uniform: this slot and the lower ones stay
+      uint32_t uk = shr1_u(kd[s]);
       uint32_t ui = shr1_u(id[s]);
-      if (s > 0) {
-        float pd = rl_f(d[s - 1], 63);
-        uint32_t pi = rl_u(id[s - 1], 63);
-        if (lane == 0) { ud = pd; ui = pi; }
+      if (s > 0) {  // lane 0 takes the last entry of the slot below
+        const uint32_t pk = rl_u(kd[s - 1], 63), pi = rl_u(id[s - 1], 63);
+        uk = lane == 0 ? pk : uk;
+        ui = lane == 0 ? pi : ui;
       }
-      uint32_t e = s * 64 + lane;
-      if (e > pos) { d[s] = ud; id[s] = ui; }
-      else if (e == pos) { d[s] = nd; id[s] = nid; }
+      const uint32_t e = (uint32_t)s * 64u + lane;
+      const bool mv = e > pos && e < cap;
+      kd[s] = mv ? uk : kd[s];
+      id[s] = mv ? ui : id[s];
+      const bool here = e == pos;
+      kd[s] = here ? nk : kd[s];
+      id[s] = here ? nid : id[s];
     }
-    len += 1;
   }
 };
+
+// One hop's pushes at once (leann.rs:953-970 run for every kept neighbour in CSR order).  With
+// C = the neighbours whose key is below the worst result at the start of the hop, the sequential
+// rule `nd < worst` admits exactly C as long as every j in C still finds fewer than ef smaller
+// keys among R and the members of C before it (checked); the resulting R is the merge of R and
+// C truncated to ef, and each of the |C| evictions lowers the worst distance when the largest
+// |C| + 1 keys of the union have pairwise different distances (checked) -- then no evicted entry
+// stays poppable and the tie list empties.  Everything else (R filling up inside the hop, equal
+// distances, more than kBatchMax candidates) returns false and takes the one-by-one loop.
+// The per-candidate loop has no serial SALU<->VALU round trip: its iterations only accumulate.
+constexpr uint32_t kBatchMax = 32;
+
+template <int S>
+__device__ __forceinline__ bool batch_insert(RSet<S>& rs, uint32_t ef, uint32_t wk0, uint64_t C,
+                                             uint32_t nk, uint32_t uid, uint32_t* mbuf) {
+  const uint32_t lane = threadIdx.x;
+  const bool full = rs.len >= ef;
+  const uint32_t nC = (uint32_t)__popcll(C);
+  if (nC > kBatchMax || (!full && rs.len + nC > ef)) return false;
+  const bool inC = (C >> lane) & 1ull;
+  uint32_t c[S], idm[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) { c[s] = 0; idm[s] = rs.id[s] & ID_MASK; }
+  uint32_t a = 0, r = 0, b = 0;
+  bool tie = false;
+  for (uint64_t rem = C; rem; rem &= rem - 1) {
+    const int j = __ffsll((long long)rem) - 1;
+    const uint32_t kj = rl_u(nk, j), ij = rl_u(uid, j);
+    uint32_t aj = 0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const bool eq = rs.kd[s] == kj;
+      const bool less = rs.kd[s] < kj || (eq && idm[s] < ij);  // this entry sorts before j
+      aj += (uint32_t)__popcll(ballot(less));
+      c[s] += less ? 0u : 1u;
+      tie |= eq;
+    }
+    const bool ceq = nk == kj && (int)lane != j;
+    const bool after = nk > kj || (ceq && uid > ij);  // j sorts before this lane's candidate
+    r += after ? 1u : 0u;
+    b += (after && (int)lane > j) ? 1u : 0u;
+    tie |= ceq && inC;
+    a = (int)lane == j ? aj : a;
+  }
+  (void)wk0;
+  if (full) {
+    if (ballot(inC && a + b >= ef)) return false;  // someone is no longer below the worst at its turn
+    if (ballot(tie)) return false;
+    // R's own largest nC + 1 distances must differ pairwise
+    bool rt = false;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      uint32_t prev = shr1_u(rs.kd[s]);
+      if (s > 0) { const uint32_t pk = rl_u(rs.kd[s - 1], 63); prev = lane == 0 ? pk : prev; }
+      const uint32_t e = (uint32_t)s * 64u + lane;
+      rt |= e >= ef - nC && e < ef && e > 0 && rs.kd[s] == prev;
+    }
+    if (ballot(rt)) return false;
+  }
+  const uint32_t newlen = rs.len + nC < ef ? rs.len + nC : ef;
+  uint32_t* mk = mbuf;
+  uint32_t* mi = mbuf + (ef + kBatchMax);
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const uint32_t e = (uint32_t)s * 64u + lane;
+    if (e < rs.len) { mk[e + c[s]] = rs.kd[s]; mi[e + c[s]] = rs.id[s]; }
+  }
+  if (inC) { mk[a + r] = nk; mi[a + r] = uid; }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const uint32_t e = (uint32_t)s * 64u + lane;
+    const bool live = e < newlen;
+    const uint32_t e2 = live ? e : 0u;
+    const uint32_t vk = mk[e2], vi = mi[e2];
+    rs.kd[s] = live ? vk : KEY_MAX;
+    rs.id[s] = live ? vi : KEY_MAX;
+  }
+  __syncthreads();
+  rs.len = newlen;
+  return true;
+}
 
 // Rust BinaryHeap ([external]: std): max-heap w.r.t. `less_eq`.  Operated by lane 0 only.
 struct ResultOrder {  // (OrderedFloat<f32>, u64), leann.rs:908
@@ -298,8 +396,10 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
   const uint32_t hmask = hcap - 1;
   const uint32_t hlimit = hcap - hcap / 8;  // load factor 0.875
   uint32_t* htab = reinterpret_cast<uint32_t*>(smem);
-  uint32_t* scratch = htab + hcap;  // 64 words for the id compaction
-  float* qs = reinterpret_cast<float*>(scratch + 64);
+  // merge buffer of batch_insert; its head doubles as the 64 words of the id compaction
+  uint32_t* mbuf = htab + hcap;
+  uint32_t* scratch = mbuf;
+  float* qs = reinterpret_cast<float*>(mbuf + 2 * (p.ef + kBatchMax));
   const uint32_t ocap = 1u << p.obits;
   const uint32_t omask = ocap - 1;
   const uint32_t olimit = ocap - ocap / 4;
@@ -343,7 +443,9 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       cV = 1;
       if (lane == 0) htab[hslot(p.entry, p.hbits)] = p.entry;
       hcount = 1;
-      rs.insert(ed, p.entry);
+      if (odd_distance(ed)) { status = QS_REDO; payload = 5; }
+      rs.insert(ordkey(ed), p.entry, ef);
+      rs.len = 1;
       if (lane == 0) plog[0] = make_uint2(__float_as_uint(ed), p.entry);
       cP = 1;
       __syncthreads();
@@ -449,29 +551,45 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       float nd = direct_distances<METRIC>(p.emb, p.stride, p.d, uid, keep, qs, q_norm, r_aux);
       ISL_MARK(tp2)  // row fetch + distances
 
-      // leann.rs:953-970 in CSR order; worst = results.peek()
+      // leann.rs:953-970 in CSR order; worst = results.peek().  NaN / -0.0 distances have no
+      // integer image: the exact kernel takes the query.
+      if (ballot((uint32_t)lane < keep && odd_distance(nd))) { status = QS_REDO; payload = 5; break; }
+      const uint32_t nk = ordkey(nd);
       uint64_t pending = keep >= 64 ? ~0ull : ((1ull << keep) - 1ull);
+      {
+        const bool full0 = rs.len >= ef;
+        const uint32_t wk0 = full0 ? rs.key_at(ef - 1) : KEY_MAX;
+        const uint64_t C = ballot(nk < wk0) & pending;
+        if (!C) { ISL_MARK(tp3) continue; }
+        if (batch_insert<S>(rs, ef, wk0, C, nk, uid, mbuf)) {
+          const uint32_t rank = (uint32_t)__popcll(C & ((1ull << lane) - 1ull));
+          if (((C >> lane) & 1ull) && cP + rank < p.plog_cap)
+            plog[cP + rank] = make_uint2(__float_as_uint(nd), uid);
+          cP += (uint32_t)__popcll(C);
+          if (full0) tcount = 0;
+          ISL_MARK(tp3)
+          continue;
+        }
+      }
       while (pending) {
-        bool full = rs.len >= ef;
-        float worst = rs.len ? rs.dist_at(rs.len - 1) : 0.0f;
-        bool pass = !full || rs.len == 0 || nd < worst;  // raw f32 `<`, leann.rs:959
-        uint64_t pm = ballot(pass) & pending;
+        const bool full = rs.len >= ef;
+        const uint32_t wk = full ? rs.key_at(ef - 1) : KEY_MAX;  // `nd < worst`, leann.rs:959
+        const uint64_t pm = ballot(nk < wk) & pending;
         if (!pm) break;
-        int r = __ffsll((long long)pm) - 1;
-        float id_d = rl_f(nd, r);
-        uint32_t id_i = rl_u(uid, r);
+        const int r = __ffsll((long long)pm) - 1;
+        const uint32_t id_k = rl_u(nk, r);
+        const uint32_t id_i = rl_u(uid, r);
         if (cP < p.plog_cap) {
-          if (lane == 0) plog[cP] = make_uint2(__float_as_uint(id_d), id_i);
+          const uint32_t id_bits = rl_u(__float_as_uint(nd), r);
+          if (lane == 0) plog[cP] = make_uint2(id_bits, id_i);
         }
         if (full) {
           // results.push + pop: the old worst leaves R but stays in the reference's candidate
           // heap.  It can only be popped again while its distance still equals the worst one.
-          float old_worst = worst;
-          uint32_t old_raw = rs.id_at(ef - 1);
-          rs.insert(id_d, id_i);
-          rs.len = ef;
-          float new_worst = rs.dist_at(ef - 1);
-          if (ordkey(old_worst) != ordkey(new_worst)) {
+          const uint32_t old_raw = rs.id_at(ef - 1);
+          rs.insert(id_k, id_i, ef);
+          const uint32_t new_wk = rs.key_at(ef - 1);
+          if (wk != new_wk) {
             tcount = 0;
           } else if (!(old_raw & FLAG_EXP)) {
             if (tcount >= 64) { status = QS_REDO; payload = 3; }
@@ -481,7 +599,8 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
             }
           }
         } else {
-          rs.insert(id_d, id_i);
+          rs.insert(id_k, id_i, ef);
+          rs.len += 1;
         }
         cP += 1;
         pending &= ~((2ull << r) - 1ull);
@@ -500,12 +619,12 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         uint32_t e = s * 64 + lane;
-        float nxt = __shfl_down(rs.d[s], 1);
+        uint32_t nxt = (uint32_t)__shfl_down((int)rs.kd[s], 1);
         if (s + 1 < S) {
-          float nd0 = rl_f(rs.d[s + 1 < S ? s + 1 : s], 0);
+          uint32_t nd0 = rl_u(rs.kd[s + 1 < S ? s + 1 : s], 0);
           if (lane == 63) nxt = nd0;
         }
-        if (e + 1 < chk && ordkey(rs.d[s]) == ordkey(nxt)) tie = true;
+        if (e + 1 < chk && rs.kd[s] == nxt) tie = true;
       }
       if (ballot(tie)) {
         if (cP <= p.plog_cap) status = QS_REPLAY;
@@ -531,7 +650,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
         uint32_t e = s * 64 + lane;
         if (e < outn) {
           p.out_ids[(uint64_t)qi * p.k + e] = (uint64_t)(rs.id[s] & ID_MASK);
-          p.out_dist[(uint64_t)qi * p.k + e] = rs.d[s];
+          p.out_dist[(uint64_t)qi * p.k + e] = key_to_dist(rs.kd[s]);
         }
       }
     }
@@ -551,8 +670,9 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       }
       if (status == QS_REDO) {
         p.redo[atomicAdd(&p.ticket[1], 1u)] = qi;
-        // why: 1 long row, 2 visited overflow, 3 tie-candidate overflow, 0 push-log overflow
-        atomicAdd(&p.ticket[8 + ((uint32_t)payload & 3u)], 1u);
+        // why: 1 long row, 2 visited overflow, 3 tie-candidate overflow, 0 push-log overflow,
+        // 5 a distance without an integer image (NaN, -0.0)
+        atomicAdd(&p.ticket[payload == 5 ? 12u : 8u + ((uint32_t)payload & 3u)], 1u);
       }
     }
     if (ovf) {  // leave the overflow table empty for the next query of this slot
@@ -812,8 +932,10 @@ struct FastGeom {
 FastGeom fast_geometry(uint32_t ef, uint32_t d) {
   // visited capacity grows with ef (V is roughly 10-30 x ef); overflow goes to HBM
   uint32_t hbits = ef <= 64 ? 10 : ef <= 160 ? 11 : ef <= 320 ? 12 : 13;
-  // query + 64 bytes: the operand prefetch of direct_group may touch one step past the end
-  size_t lds = ((size_t)4 << hbits) + 64 * 4 + (size_t)((d + 3) / 4 * 4) * 4 + 64;
+  // visited table, merge buffer, query (+ 64 bytes when d is not a multiple of 16: the operand
+  // prefetch of direct_group may touch the rest of the last step)
+  size_t lds = ((size_t)4 << hbits) + (size_t)(ef + kBatchMax) * 8 + (size_t)((d + 3) / 4 * 4) * 4 +
+               ((d & 15) ? 64 : 0);
   return {hbits, lds};
 }
 
@@ -1180,9 +1302,9 @@ isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws) {
   }
   if (getenv("ISL_DEBUG") && (head[1] || head[3])) {
     fprintf(stderr, "[isl] %u of %llu queries re-run by the exact kernel (fast kernel %s): "
-            "long-row %u, visited-overflow %u, tie-candidate overflow %u, push-log overflow %u; "
-            "%u re-ordered by the replay kernel\n", head[1], (unsigned long long)nq,
-            use_fast ? "on" : "off", head[9], head[10], head[11], head[8], head[3]);
+            "long-row %u, visited-overflow %u, tie-candidate overflow %u, push-log overflow %u, "
+            "NaN/-0 distance %u; %u re-ordered by the replay kernel\n", head[1], (unsigned long long)nq,
+            use_fast ? "on" : "off", head[9], head[10], head[11], head[8], head[12], head[3]);
   }
   for (uint64_t i = 0; i < nq; i++) {  // first failing query wins, like the sequential map
     if (status[i] == QS_OK) continue;

@@ -19,4 +19,4 @@ torch.cuda.synchronize()
 for it in range(reps):
     idx.search_batch_device(q.data_ptr(), nq, d, 10, ef, oi.data_ptr(), od.data_ptr(), oc.data_ptr())
     st = idx.last_stats()
-    print(f"N={N} nq={nq} ef={ef} kernel_ms={st['kernel_ms']:.3f} evals/q={st['evals']/nq:.0f} hops/q={st['expansions']/nq:.0f} GB/s={st['evals']*d*4/st['kernel_ms']/1e6:.0f} replay={st['replayed']}")
+    print(f"N={N} nq={nq} ef={ef} kernel_ms={st['kernel_ms']:.3f} evals/q={st['evals']/nq:.0f} hops/q={st['expansions']/nq:.0f} GB/s={st['evals']*d*4/st['kernel_ms']/1e6:.0f} replay={st['replayed']} pushes/q={st['pushes']/nq:.0f}")
