@@ -26,7 +26,7 @@ import os
 import sys
 
 # one hardware queue per search lane in flight (the HIP default is 4 queues per process)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import threading
 import time
 
@@ -107,8 +107,8 @@ def cpu_baseline(x, offsets, neighbours, entry, queries, k, ef, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--nq", type=int, default=1024)
@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--mode", choices=["shard", "replica"], default="shard")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct-batches", type=int, default=4)
-    ap.add_argument("--pipeline", type=int, default=3,
+    ap.add_argument("--pipeline", type=int, default=8,
                     help="searches kept in flight (isl_search_batch_device_async); 1 = synchronous")
     args = ap.parse_args()
 
@@ -189,7 +189,7 @@ def main():
         truths.append((ti + lo, td))
     torch.cuda.synchronize()
 
-    depth = max(1, min(args.pipeline, 8))
+    depth = max(1, min(args.pipeline, 16))
     # one output set per search in flight
     outs = [(torch.zeros((nq, k), dtype=torch.int64, device=dev),
              torch.zeros((nq, k), dtype=torch.float32, device=dev),

@@ -9,6 +9,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# One hardware queue per search in flight: up to 16 searches may overlap on their own streams
+# (isl_search_batch_device_async), the HIP default of 4 queues per process would serialise them.
+# Must be in the environment before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libislands_amd.so")
 

@@ -78,6 +78,11 @@ void free_workspace(SearchWorkspace& ws) {
 
 using namespace isl;
 
+// Up to kSearchLanes searches overlap on their own streams; the runtime's default of 4 hardware
+// queues per process would make them share queues and serialise.  Effective when the library is
+// loaded before the HIP runtime initialises (an explicit setting in the environment wins).
+__attribute__((constructor)) static void isl_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "32", 0); }
+
 extern "C" {
 
 const char* isl_last_error_message(void) { return last_error().message.c_str(); }

@@ -88,7 +88,7 @@ struct SearchWorkspace {
   uint64_t* d_prof = nullptr;    // ISL_DEBUG phase timers of the call in flight
 };
 
-constexpr int kSearchLanes = 8;  // independent workspaces = searches that may be in flight
+constexpr int kSearchLanes = 16;  // independent workspaces = searches that may be in flight
 
 }  // namespace isl
 
