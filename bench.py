@@ -295,7 +295,17 @@ def main():
     bytes_per_launch = algorithmic_bytes(agg, d, k) / max(args.steps, 1)
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     agg_gbs = algorithmic_bytes(agg, d, k) / elapsed / 1e9
+    # HBM bytes per launch come from a separate rocprofv3 --pmc FETCH_SIZE pass (counters cannot be
+    # read from inside this process); the committed measurement applies to the headline workload only
     traffic_env = os.environ.get("ISL_TRAFFIC_BYTES")
+    traffic_src = None
+    if not traffic_env and world == 1 and (N, d, nq, ef, k) == (10_000_000, 768, 1024, 128, 10):
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch.json")) as fh:
+                traffic_env = str(json.load(fh)["search"]["hbm_bytes_per_launch"])
+                traffic_src = "profiles/r01_pmc_fetch.json (rocprofv3 --pmc FETCH_SIZE x 1024 x 2)"
+        except (OSError, KeyError, ValueError):
+            traffic_env = None
 
     result = {
         "metric": "queries/sec @ recall@10>=0.95, 10Mx768 ef=128",
@@ -333,6 +343,7 @@ def main():
             "bound": "hbm", "achieved": round(agg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(agg_gbs / HBM_PEAK_GBS, 4),
             "traffic": float(traffic_env) if traffic_env else None,
+            "traffic_source": traffic_src,
             "kernel": "leann_search_fast<2,cosine>",
             "launches_overlapped": depth,
             "per_launch": {"kernel_ms": round(kernel_ms, 3), "achieved": round(achieved, 1),

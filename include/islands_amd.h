@@ -165,7 +165,7 @@ isl_status isl_search_batch_device(const isl_index* idx, const float* d_queries,
                                    uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_out_ids,
                                    float* d_out_dist, uint32_t* d_out_count, void* stream);
 /* Asynchronous form: enqueues the search on one of the index's private streams (ordered after
- * the work already enqueued on `stream`) and returns at once; up to 4 searches may be in
+ * the work already enqueued on `stream`) and returns at once; up to 16 searches may be in
  * flight, so consecutive batches overlap and the slowest queries of one batch no longer idle
  * the chip.  Outputs are valid and the per-query status is reported once isl_search_wait
  * returns for *token (token 0 = the call was answered immediately). */
