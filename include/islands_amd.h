@@ -219,6 +219,16 @@ isl_status isl_merge_topk(uint64_t nlists, uint64_t nq, uint64_t k, const uint64
                           uint64_t top_k, uint64_t* out_ids, float* out_scores,
                           uint32_t* out_src, uint32_t* out_count, int32_t mem, int32_t device,
                           void* stream);
+/* Product-level merge, src/indexer/service.rs:775-801 (IndexerService::search_with_embeddings):
+ * per list the (id, distance) results of one index (searched with ef = max(top_k, 100), :781);
+ * results whose id has no file entry are dropped (`files_len[l]` = stored.files.len(), host
+ * array, NULL = keep all, :788), score = 1.0 - distance (:791), stable sort by score descending
+ * (:800), truncate to top_k.  Layouts as in isl_merge_topk. */
+isl_status isl_merge_service(uint64_t nlists, uint64_t nq, uint64_t k, const uint64_t* ids,
+                             const float* distances, const uint32_t* counts,
+                             const uint64_t* files_len, uint64_t top_k, uint64_t* out_ids,
+                             float* out_scores, uint32_t* out_src, uint32_t* out_count,
+                             int32_t mem, int32_t device, void* stream);
 
 /* ---- pq.rs ---- */
 typedef struct isl_pq isl_pq;
@@ -239,6 +249,43 @@ isl_status isl_pq_asymmetric_distance(const isl_pq* pq, const float* query, uint
 /* encode, pq.rs:221-244: n vectors -> [n][m] u16 codes. */
 isl_status isl_pq_encode(const isl_pq* pq, const float* vectors, uint64_t n, uint64_t d,
                          uint16_t* codes, int32_t mem, void* stream);
+
+/* ---- embedding/candle_provider.rs:353-507: the recompute encoder (CandleEmbedder) ----
+ * The model is candle-transformers 0.9.1 `BertModel` (third party, not in the reference tree;
+ * call sites candle_provider.rs:284, :429-432); its published algorithm runs here in float32,
+ * the linear layers on the matrix cores.  isl_bert_config mirrors the fields of the
+ * checkpoint's config.json that the forward pass uses. */
+typedef struct isl_bert_config {
+  uint32_t vocab_size;
+  uint32_t hidden;        /* hidden_size */
+  uint32_t layers;        /* num_hidden_layers */
+  uint32_t heads;         /* num_attention_heads; hidden / heads in {16, 32, 64} */
+  uint32_t intermediate;  /* intermediate_size */
+  uint32_t max_position;  /* max_position_embeddings */
+  uint32_t type_vocab;    /* type_vocab_size */
+  float layer_norm_eps;
+  uint32_t gelu_tanh;     /* 0: hidden_act "gelu" (erf), 1: "gelu_new"/approximate (tanh) */
+} isl_bert_config;
+typedef struct isl_encoder isl_encoder;
+isl_status isl_encoder_new(const isl_bert_config* cfg, int32_t device, isl_encoder** out);
+void isl_encoder_free(isl_encoder* enc);
+/* One tensor of the checkpoint by its HuggingFace name ("embeddings.word_embeddings.weight",
+ * "encoder.layer.0.attention.self.query.weight", ...; an optional "bert." prefix is ignored), the
+ * names candle's VarBuilder resolves (candle_provider.rs:267-284).  A wrong element count is
+ * DimensionMismatch{expected, actual}. */
+isl_status isl_encoder_set_weight(isl_encoder* enc, const char* name, const float* data,
+                                  uint64_t count, int32_t mem);
+/* BertModel::forward(input_ids, token_type_ids, Some(attention_mask)), candle_provider.rs:429-432:
+ * ids [B, L] (already padded per :385-402), token_type_ids NULL = zeros, attention_mask [B, L]
+ * of 0.0 / 1.0, NULL = ones -> last hidden state [B, L, hidden]. */
+isl_status isl_encoder_forward(isl_encoder* enc, const int64_t* input_ids,
+                               const int64_t* token_type_ids, const float* attention_mask,
+                               uint64_t B, uint64_t L, float* out_hidden, int32_t mem, void* stream);
+/* embed_texts_raw after tokenisation (candle_provider.rs:404-507): forward, masked mean pooling,
+ * L2 normalisation when `normalize` -> [B, hidden]. */
+isl_status isl_encoder_embed(isl_encoder* enc, const int64_t* input_ids, const int64_t* token_type_ids,
+                             const float* attention_mask, uint64_t B, uint64_t L, int32_t normalize,
+                             float* out, int32_t mem, void* stream);
 
 /* ---- embedding/candle_provider.rs:434-488: masked mean-pool + optional L2 normalise ----
  * hidden [B][L][H] f32, mask [B][L] (0/1 as f32), out [B][H].  The BERT forward that

@@ -15,14 +15,14 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _ffi
-from ._ffi import LeannConfigC, SearchStatsC
+from ._ffi import BertConfigC, LeannConfigC, SearchStatsC
 
 __all__ = [
     "CoreError", "DistanceMetric", "PruningStrategy", "LeannConfig", "CsrGraph",
     "InMemoryEmbeddingProvider", "LeannIndex", "ProductQuantizer", "SearchResult",
-    "batch_calculate", "calculate", "calculate_squared", "normalize_rows", "merge_topk",
+    "batch_calculate", "calculate", "calculate_squared", "normalize_rows", "merge_topk", "merge_service",
     "device_count", "HnswGraph", "SearchConfig", "Searcher", "MultiIndexSearcher",
-    "mean_pool_normalize",
+    "mean_pool_normalize", "BertConfig", "CandleEmbedder",
 ]
 
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -442,6 +442,25 @@ def merge_topk(ids, scores, counts, top_k: int, id_base=None, device: int = 0):
     return oi[:, :top_k], osc[:, :top_k], osrc[:, :top_k], oc
 
 
+def merge_service(ids, distances, counts, top_k: int, files_len=None, device: int = 0):
+    """Cross-index merge of IndexerService::search_with_embeddings (indexer/service.rs:775-801):
+    ids without a file entry dropped, score = 1 - distance, stable sort by score descending,
+    truncate.  ids/distances: [nlists, nq, k]; counts: [nlists, nq].  Returns (ids, scores, src, count)."""
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    distances = _f32(distances)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    nl, nq, k = ids.shape
+    fl = None if files_len is None else np.ascontiguousarray(files_len, dtype=np.uint64)
+    oi = np.zeros((nq, max(top_k, 1)), dtype=np.uint64)
+    osc = np.zeros((nq, max(top_k, 1)), dtype=np.float32)
+    osrc = np.zeros((nq, max(top_k, 1)), dtype=np.uint32)
+    oc = np.zeros(nq, dtype=np.uint32)
+    _check(_ffi.lib().isl_merge_service(nl, nq, k, _ptr(ids), _ptr(distances), _ptr(counts),
+                                        None if fl is None else _ptr(fl), top_k, _ptr(oi),
+                                        _ptr(osc), _ptr(osrc), _ptr(oc), MEM_HOST, device, None))
+    return oi[:, :top_k], osc[:, :top_k], osrc[:, :top_k], oc
+
+
 # --------------------------------------------------------------------- pq.rs
 class ProductQuantizer:
     """ProductQuantizer with trained codebooks (pq.rs:116-348); training (k-means) is out of
@@ -725,3 +744,76 @@ def mean_pool_normalize(hidden, mask, normalize: bool = True, device: int = 0) -
     _check(_ffi.lib().isl_mean_pool_normalize(_ptr(h), _ptr(mk), B, L, H, int(normalize),
                                               _ptr(out), MEM_HOST, device, None))
     return out
+
+
+@dataclass
+class BertConfig:
+    """The config.json fields BertModel's forward pass uses (candle_provider.rs:258-284)."""
+    vocab_size: int = 30522
+    hidden: int = 384
+    layers: int = 6
+    heads: int = 12
+    intermediate: int = 1536
+    max_position: int = 512
+    type_vocab: int = 2
+    layer_norm_eps: float = 1e-12
+    gelu_tanh: bool = False
+
+    def _to_c(self) -> BertConfigC:
+        return BertConfigC(self.vocab_size, self.hidden, self.layers, self.heads, self.intermediate,
+                           self.max_position, self.type_vocab, self.layer_norm_eps, int(self.gelu_tanh))
+
+
+class CandleEmbedder:
+    """Device twin of CandleEmbedder (candle_provider.rs:226-507) after tokenisation: weights by
+    their checkpoint names, `embed` = embed_texts_raw on padded token ids."""
+
+    def __init__(self, config: BertConfig, weights: dict | None = None, normalize: bool = True,
+                 device: int = 0):
+        self.config, self.normalize, self.device = config, normalize, device
+        h = C.c_void_p()
+        c = config._to_c()
+        _check(_ffi.lib().isl_encoder_new(C.byref(c), device, C.byref(h)))
+        self._h = h
+        for name, value in (weights or {}).items():
+            self.set_weight(name, value)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                _ffi.lib().isl_encoder_free(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    def set_weight(self, name: str, value) -> None:
+        v = _f32(value)
+        _check(_ffi.lib().isl_encoder_set_weight(self._h, name.encode(), _ptr(v), v.size, MEM_HOST))
+
+    def dimension(self) -> int:
+        return self.config.hidden
+
+    @staticmethod
+    def _inputs(input_ids, token_type_ids, attention_mask):
+        ids = np.ascontiguousarray(input_ids, dtype=np.int64)
+        tt = None if token_type_ids is None else np.ascontiguousarray(token_type_ids, dtype=np.int64)
+        mk = None if attention_mask is None else _f32(attention_mask)
+        return ids, tt, mk
+
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None) -> np.ndarray:
+        ids, tt, mk = self._inputs(input_ids, token_type_ids, attention_mask)
+        B, L = ids.shape
+        out = np.zeros((B, L, self.config.hidden), dtype=np.float32)
+        _check(_ffi.lib().isl_encoder_forward(self._h, _ptr(ids), None if tt is None else _ptr(tt),
+                                              None if mk is None else _ptr(mk), B, L, _ptr(out),
+                                              MEM_HOST, None))
+        return out
+
+    def embed(self, input_ids, token_type_ids=None, attention_mask=None) -> np.ndarray:
+        ids, tt, mk = self._inputs(input_ids, token_type_ids, attention_mask)
+        B, L = ids.shape
+        out = np.zeros((B, self.config.hidden), dtype=np.float32)
+        _check(_ffi.lib().isl_encoder_embed(self._h, _ptr(ids), None if tt is None else _ptr(tt),
+                                            None if mk is None else _ptr(mk), B, L,
+                                            int(self.normalize), _ptr(out), MEM_HOST, None))
+        return out

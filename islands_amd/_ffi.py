@@ -31,6 +31,13 @@ class LeannConfigC(C.Structure):
     ]
 
 
+class BertConfigC(C.Structure):
+    """isl_bert_config (config.json fields used by the forward pass)."""
+    _fields_ = [("vocab_size", u32), ("hidden", u32), ("layers", u32), ("heads", u32),
+                ("intermediate", u32), ("max_position", u32), ("type_vocab", u32),
+                ("layer_norm_eps", f32), ("gelu_tanh", u32)]
+
+
 class SearchStatsC(C.Structure):
     _fields_ = [("queries", u64), ("expansions", u64), ("edges", u64), ("evals", u64),
                 ("pushes", u64), ("exact_path", u64), ("replayed", u64), ("kernel_ms", C.c_double)]
@@ -87,6 +94,16 @@ SIGNATURES = {
     "isl_merge_topk": (i32, [u64, u64, u64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u64,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, i32, i32,
                              C.c_void_p]),
+    "isl_merge_service": (i32, [u64, u64, u64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u64,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, i32, i32,
+                             C.c_void_p]),
+    "isl_encoder_new": (i32, [P(BertConfigC), i32, P(C.c_void_p)]),
+    "isl_encoder_free": (None, [C.c_void_p]),
+    "isl_encoder_set_weight": (i32, [C.c_void_p, C.c_char_p, C.c_void_p, u64, i32]),
+    "isl_encoder_forward": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u64, u64,
+                                  C.c_void_p, i32, C.c_void_p]),
+    "isl_encoder_embed": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u64, u64, i32,
+                                C.c_void_p, i32, C.c_void_p]),
     "isl_mean_pool_normalize": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, i32, C.c_void_p, i32,
                                       i32, C.c_void_p]),
     "isl_hnsw_from_layers": (i32, [u64, u64, u64, i32, u64, u64, u64, C.c_void_p, C.c_void_p,

@@ -1,0 +1,515 @@
+// Recompute encoder of the LEANN path: CandleEmbedder::embed_texts_raw,
+// src/core/embedding/candle_provider.rs:353-507 -- BERT forward (:429-432), masked mean pooling
+// (:434-463), optional L2 normalisation (:466-488).
+//
+// The model is third-party code that is not in the reference tree (candle-transformers 0.9.1
+// `models::bert::BertModel`, Cargo.lock:1113-1114; a port of HuggingFace modeling_bert.py).  Its
+// published algorithm is what runs here, in float32 like the reference's CPU path:
+//   embeddings = word + token_type + position -> LayerNorm
+//   per layer:  QKV = x W^T + b (one fused GEMM) -> softmax(Q K^T / sqrt(dh) + (1-mask)*f32::MIN) V
+//               -> dense + residual -> LayerNorm -> dense + GELU -> dense + residual -> LayerNorm
+// The linear layers (>98 % of the flops: 24 h^2 L of 24 h^2 L + 4 L^2 h per layer and sequence)
+// run on the matrix cores with v_mfma_f32_32x32x2_f32; attention, LayerNorm and the embedding
+// gather are VALU kernels.  Every output row depends on its own sequence only and is reduced in a
+// fixed order, so a node's embedding does not depend on what it is batched with.
+#include "common.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct isl_encoder {
+  isl_bert_config cfg{};
+  int device = -1;
+  float *word = nullptr, *pos = nullptr, *type = nullptr, *eln_w = nullptr, *eln_b = nullptr;
+  struct Layer {
+    float *wqkv = nullptr, *bqkv = nullptr, *wo = nullptr, *bo = nullptr, *ln1w = nullptr,
+          *ln1b = nullptr, *wi = nullptr, *bi = nullptr, *wo2 = nullptr, *bo2 = nullptr,
+          *ln2w = nullptr, *ln2b = nullptr;
+  };
+  std::vector<Layer> layers;
+  std::vector<void*> owned;
+  // workspace, grown on demand (tokens = sequences * padded length)
+  uint64_t ws_tokens = 0;
+  float *x = nullptr, *x1 = nullptr, *t = nullptr, *qkv = nullptr, *ctx = nullptr, *inter = nullptr;
+  float* d_mask = nullptr;
+  int64_t *d_ids = nullptr, *d_tt = nullptr;
+  uint32_t* d_flag = nullptr;
+  std::mutex mu;
+};
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// LayerNorm of one token row held in LDS (`row`, h floats): biased variance of the centred
+// values, eps inside the square root (candle_nn::LayerNorm / torch.nn.LayerNorm).
+__device__ __forceinline__ void ln_row(const float* row, uint32_t h, const float* __restrict__ w,
+                                       const float* __restrict__ b, float eps, float* __restrict__ out) {
+  const uint32_t lane = threadIdx.x;
+  float s = 0.0f;
+  for (uint32_t j = lane; j < h; j += 64) s += row[j];
+  const float mean = wave_sum(s) / (float)h;
+  float v = 0.0f;
+  for (uint32_t j = lane; j < h; j += 64) { float c = row[j] - mean; v += c * c; }
+  const float var = wave_sum(v) / (float)h;
+  const float inv = 1.0f / sqrtf(var + eps);
+  for (uint32_t j = lane; j < h; j += 64) out[j] = (row[j] - mean) * inv * w[j] + b[j];
+}
+
+// BertEmbeddings: word + token_type + position -> LayerNorm.  One wave per token.
+__global__ __launch_bounds__(64) void embed_ln_kernel(const int64_t* __restrict__ ids,
+                                                      const int64_t* __restrict__ tt, uint32_t L,
+                                                      uint32_t h, uint32_t vocab, uint32_t ntypes,
+                                                      const float* __restrict__ word,
+                                                      const float* __restrict__ pos,
+                                                      const float* __restrict__ type,
+                                                      const float* __restrict__ w,
+                                                      const float* __restrict__ b, float eps,
+                                                      float* __restrict__ out, uint32_t* flag) {
+  extern __shared__ float row[];
+  const uint64_t tok = blockIdx.x;
+  const uint32_t p = (uint32_t)(tok % L);
+  int64_t id = ids[tok], ty = tt ? tt[tok] : 0;
+  if (id < 0 || id >= (int64_t)vocab || ty < 0 || ty >= (int64_t)ntypes) {
+    if (threadIdx.x == 0) atomicOr(flag, 1u);
+    id = 0;
+    ty = 0;
+  }
+  for (uint32_t j = threadIdx.x; j < h; j += 64)
+    row[j] = word[(uint64_t)id * h + j] + type[(uint64_t)ty * h + j] + pos[(uint64_t)p * h + j];
+  __syncthreads();
+  ln_row(row, h, w, b, eps, out + tok * h);
+}
+
+// y = LayerNorm(a) (the residual is already added by the GEMM epilogue).  One wave per token.
+__global__ __launch_bounds__(64) void ln_kernel(const float* __restrict__ a, uint32_t h,
+                                                const float* __restrict__ w,
+                                                const float* __restrict__ b, float eps,
+                                                float* __restrict__ out) {
+  extern __shared__ float row[];
+  const uint64_t tok = blockIdx.x;
+  for (uint32_t j = threadIdx.x; j < h; j += 64) row[j] = a[tok * h + j];
+  __syncthreads();
+  ln_row(row, h, w, b, eps, out + tok * h);
+}
+
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x / 1.41421356237309515f)); }
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+
+// C[M,N] = A[M,K] W[N,K]^T + bias (+ R) with an optional GELU: Linear layers of the encoder.
+// 128x128 tile per 256-thread workgroup, 64x64 per wave = 2x2 MFMA 32x32 blocks, K in slabs of
+// 16 staged k-major in LDS (the next slab is fetched into registers while the current one feeds
+// the matrix cores).  v_mfma_f32_32x32x2_f32: lane l supplies A[l%32][l/32] and B[l/32][l%32],
+// accumulator register r of lane l is C[8*(r/4) + 4*(l/32) + r%4][l%32].
+constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 4;
+template <int ACT, bool RES>
+__global__ __launch_bounds__(256) void gemm_tn_f32(const float* __restrict__ A,
+                                                   const float* __restrict__ W,
+                                                   const float* __restrict__ bias,
+                                                   const float* __restrict__ R, float* __restrict__ C,
+                                                   uint32_t M, uint32_t N, uint32_t K) {
+  __shared__ float As[BK][LDT];
+  __shared__ float Bs[BK][LDT];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const uint64_t m0 = (uint64_t)blockIdx.y * BM, n0 = (uint64_t)blockIdx.x * BN;
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  // this thread's two float4 of the A slab and of the W slab: row = idx / 4, k-quad = idx % 4
+  const uint32_t r0 = tid >> 2, r1 = (tid + 256) >> 2, kq = (tid & 3) * 4;
+  float4 pa0, pa1, pb0, pb1;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch = [&](uint32_t k0) {
+    const bool kin = k0 + kq < K;  // K is a multiple of 4 (checked on the host)
+    pa0 = (kin && m0 + r0 < M) ? *reinterpret_cast<const float4*>(A + (m0 + r0) * K + k0 + kq) : zero;
+    pa1 = (kin && m0 + r1 < M) ? *reinterpret_cast<const float4*>(A + (m0 + r1) * K + k0 + kq) : zero;
+    pb0 = (kin && n0 + r0 < N) ? *reinterpret_cast<const float4*>(W + (n0 + r0) * K + k0 + kq) : zero;
+    pb1 = (kin && n0 + r1 < N) ? *reinterpret_cast<const float4*>(W + (n0 + r1) * K + k0 + kq) : zero;
+  };
+  auto stage = [&]() {
+    As[kq + 0][r0] = pa0.x; As[kq + 1][r0] = pa0.y; As[kq + 2][r0] = pa0.z; As[kq + 3][r0] = pa0.w;
+    As[kq + 0][r1] = pa1.x; As[kq + 1][r1] = pa1.y; As[kq + 2][r1] = pa1.z; As[kq + 3][r1] = pa1.w;
+    Bs[kq + 0][r0] = pb0.x; Bs[kq + 1][r0] = pb0.y; Bs[kq + 2][r0] = pb0.z; Bs[kq + 3][r0] = pb0.w;
+    Bs[kq + 0][r1] = pb1.x; Bs[kq + 1][r1] = pb1.y; Bs[kq + 2][r1] = pb1.z; Bs[kq + 3][r1] = pb1.w;
+  };
+  fetch(0);
+  const uint32_t kh = lane >> 5, c32 = lane & 31;
+  for (uint32_t k0 = 0; k0 < K; k0 += BK) {
+    stage();
+    __syncthreads();
+    if (k0 + BK < K) fetch(k0 + BK);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const float a0 = As[2 * kk + kh][wm + c32], a1 = As[2 * kk + kh][wm + 32 + c32];
+      const float b0 = Bs[2 * kk + kh][wn + c32], b1 = Bs[2 * kk + kh][wn + 32 + c32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint64_t n = n0 + wn + j * 32 + c32;
+      if (n >= N) continue;
+      const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint64_t m = m0 + wm + i * 32 + 8 * (r / 4) + 4 * kh + (r % 4);
+        if (m >= M) continue;
+        float v = acc[i][j][r] + bv;
+        if (ACT == 1) v = gelu_erf_f(v);
+        if (ACT == 2) v = gelu_tanh_f(v);
+        if (RES) v += R[m * N + n];
+        C[m * N + n] = v;
+      }
+    }
+}
+
+// BertSelfAttention for one (sequence, head) and 64 query rows per wave: lane i owns query row
+// i.  Keys / values of the head are staged through LDS 64 at a time; scores of the chunk go to
+// an LDS row per lane, the softmax is carried online across chunks (running max / sum).
+// scores = q.k / sqrt(dh) + (1 - mask[key]) * f32::MIN, exactly candle's broadcast_add of the
+// extended mask; padded query rows are computed like any other (the reference does, too).
+template <int DH>
+__global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__ qkv,
+                                                       const float* __restrict__ mask, uint32_t L,
+                                                       uint32_t heads, float* __restrict__ ctx) {
+  __shared__ float Ks[64][DH + 4];
+  __shared__ float Vs[64][DH + 4];
+  __shared__ float Ss[64][65];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t b = blockIdx.x / heads, hd = blockIdx.x % heads;
+  const uint32_t h = heads * DH, ld = 3 * h;
+  const uint32_t qi = blockIdx.y * 64 + lane;
+  const bool qok = qi < L;
+  const float scale = sqrtf((float)DH);
+  float q[DH], acc[DH];
+  {
+    const float* qp = qkv + ((uint64_t)b * L + (qok ? qi : 0)) * ld + hd * DH;
+#pragma unroll
+    for (int c = 0; c < DH; c += 4) {
+      float4 v = *reinterpret_cast<const float4*>(qp + c);
+      q[c] = v.x; q[c + 1] = v.y; q[c + 2] = v.z; q[c + 3] = v.w;
+    }
+#pragma unroll
+    for (int c = 0; c < DH; ++c) acc[c] = 0.0f;
+  }
+  float mrun = -INFINITY, lrun = 0.0f;
+  for (uint32_t j0 = 0; j0 < L; j0 += 64) {
+    const uint32_t nk = L - j0 < 64 ? L - j0 : 64;
+    __syncthreads();
+    // stage K and V rows j0 .. j0+nk: 64 lanes x float4 cover 4 rows of DH=64 (or 8 of DH=32)
+    constexpr int LPR = DH / 4;  // lanes per row
+    for (uint32_t rr = lane / LPR; rr < nk; rr += 64 / LPR) {
+      const uint32_t c = (lane % LPR) * 4;
+      const float* base = qkv + ((uint64_t)b * L + j0 + rr) * ld + hd * DH + c;
+      float4 kv = *reinterpret_cast<const float4*>(base + h);
+      float4 vv = *reinterpret_cast<const float4*>(base + 2 * h);
+      Ks[rr][c] = kv.x; Ks[rr][c + 1] = kv.y; Ks[rr][c + 2] = kv.z; Ks[rr][c + 3] = kv.w;
+      Vs[rr][c] = vv.x; Vs[rr][c + 1] = vv.y; Vs[rr][c + 2] = vv.z; Vs[rr][c + 3] = vv.w;
+    }
+    __syncthreads();
+    float cmax = -INFINITY;
+    for (uint32_t j = 0; j < nk; ++j) {
+      float s = 0.0f;
+#pragma unroll
+      for (int c = 0; c < DH; c += 4) {
+        float4 kv = *reinterpret_cast<const float4*>(&Ks[j][c]);
+        s += q[c] * kv.x; s += q[c + 1] * kv.y; s += q[c + 2] * kv.z; s += q[c + 3] * kv.w;
+      }
+      s = s / scale + (1.0f - mask[(uint64_t)b * L + j0 + j]) * -3.40282347e+38f;
+      Ss[lane][j] = s;
+      cmax = fmaxf(cmax, s);
+    }
+    const float mnew = fmaxf(mrun, cmax);
+    const float corr = expf(mrun - mnew);  // first chunk: exp(-inf) = 0
+    lrun *= corr;
+#pragma unroll
+    for (int c = 0; c < DH; ++c) acc[c] *= corr;
+    for (uint32_t j = 0; j < nk; ++j) {
+      const float p = expf(Ss[lane][j] - mnew);
+      lrun += p;
+#pragma unroll
+      for (int c = 0; c < DH; c += 4) {
+        float4 vv = *reinterpret_cast<const float4*>(&Vs[j][c]);
+        acc[c] += p * vv.x; acc[c + 1] += p * vv.y; acc[c + 2] += p * vv.z; acc[c + 3] += p * vv.w;
+      }
+    }
+    mrun = mnew;
+  }
+  if (qok) {
+    float* op = ctx + ((uint64_t)b * L + qi) * h + hd * DH;
+    const float inv = 1.0f / lrun;
+#pragma unroll
+    for (int c = 0; c < DH; c += 4)
+      *reinterpret_cast<float4*>(op + c) = make_float4(acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv);
+  }
+}
+
+// masked mean pooling + optional L2 normalisation, candle_provider.rs:434-488; one wave per
+// sequence, lane j owns hidden units j, j+64, ...; sequential over the tokens.
+__global__ __launch_bounds__(64) void pool_kernel(const float* __restrict__ hid,
+                                                  const float* __restrict__ mask, uint32_t L,
+                                                  uint32_t h, int normalize, float* __restrict__ out) {
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  float sm = 0.0f;
+  for (uint32_t t = 0; t < L; ++t) sm += mask[(uint64_t)b * L + t];
+  if (sm < 1e-9f) sm = 1e-9f;
+  float ss = 0.0f;
+  for (uint32_t j = lane; j < h; j += 64) {
+    float s = 0.0f;
+    for (uint32_t t = 0; t < L; ++t) s += hid[((uint64_t)b * L + t) * h + j] * mask[(uint64_t)b * L + t];
+    s = s / sm;
+    out[(uint64_t)b * h + j] = s;
+    ss += s * s;
+  }
+  if (normalize) {
+    float norm = sqrtf(wave_sum(ss));
+    if (norm < 1e-12f) norm = 1e-12f;
+    for (uint32_t j = lane; j < h; j += 64) out[(uint64_t)b * h + j] = out[(uint64_t)b * h + j] / norm;
+  }
+}
+
+template <int ACT, bool RES>
+void launch_gemm(const float* A, const float* W, const float* bias, const float* R, float* C,
+                 uint64_t M, uint64_t N, uint64_t K, hipStream_t st) {
+  dim3 grid((uint32_t)((N + BN - 1) / BN), (uint32_t)((M + BM - 1) / BM));
+  hipLaunchKernelGGL((gemm_tn_f32<ACT, RES>), grid, dim3(256), 0, st, A, W, bias, R, C, (uint32_t)M,
+                     (uint32_t)N, (uint32_t)K);
+}
+
+isl_status ensure_ws(isl_encoder* e, uint64_t B, uint64_t L) {
+  const uint64_t tokens = B * L;
+  if (tokens <= e->ws_tokens) return ISL_OK;
+  void* olds[] = {e->x, e->x1, e->t, e->qkv, e->ctx, e->inter, e->d_mask, e->d_ids, e->d_tt};
+  for (void* p : olds)
+    if (p) (void)hipFree(p);
+  e->x = e->x1 = e->t = e->qkv = e->ctx = e->inter = e->d_mask = nullptr;
+  e->d_ids = e->d_tt = nullptr;
+  e->ws_tokens = 0;
+  const uint64_t h = e->cfg.hidden, I = e->cfg.intermediate;
+  if (hipMalloc(&e->x, tokens * h * 4) != hipSuccess || hipMalloc(&e->x1, tokens * h * 4) != hipSuccess ||
+      hipMalloc(&e->t, tokens * h * 4) != hipSuccess || hipMalloc(&e->qkv, tokens * 3 * h * 4) != hipSuccess ||
+      hipMalloc(&e->ctx, tokens * h * 4) != hipSuccess || hipMalloc(&e->inter, tokens * I * 4) != hipSuccess ||
+      hipMalloc(&e->d_mask, tokens * 4) != hipSuccess || hipMalloc(&e->d_ids, tokens * 8) != hipSuccess ||
+      hipMalloc(&e->d_tt, tokens * 8) != hipSuccess)
+    return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed for the encoder workspace (%llu tokens)",
+                     (unsigned long long)tokens);
+  e->ws_tokens = tokens;
+  return ISL_OK;
+}
+
+__global__ void fill_f32(float* p, uint64_t n, float v) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// Runs the model on B sequences of padded length L; the last hidden state is left in e->x.
+isl_status run_forward(isl_encoder* e, const int64_t* ids, const int64_t* tt, const float* mask,
+                       uint64_t B, uint64_t L, int32_t mem, hipStream_t st) {
+  const isl_bert_config& c = e->cfg;
+  if (L > c.max_position)
+    return isl::fail(ISL_ERR_EMBEDDING, "Embedding error: sequence length %llu exceeds max_position %u",
+                     (unsigned long long)L, c.max_position);
+  ISL_TRY(ensure_ws(e, B, L));
+  const uint64_t M = B * L, h = c.hidden, I = c.intermediate;
+  hipMemcpyKind kind = mem == ISL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  ISL_HIP(hipMemcpyAsync(e->d_ids, ids, M * 8, kind, st));
+  if (tt) ISL_HIP(hipMemcpyAsync(e->d_tt, tt, M * 8, kind, st));
+  if (mask) ISL_HIP(hipMemcpyAsync(e->d_mask, mask, M * 4, kind, st));
+  else hipLaunchKernelGGL(fill_f32, dim3((uint32_t)((M + 255) / 256)), dim3(256), 0, st, e->d_mask, M, 1.0f);
+  ISL_HIP(hipMemsetAsync(e->d_flag, 0, 4, st));
+  hipLaunchKernelGGL(embed_ln_kernel, dim3((uint32_t)M), dim3(64), h * 4, st, e->d_ids,
+                     tt ? e->d_tt : nullptr, (uint32_t)L, (uint32_t)h, c.vocab_size, c.type_vocab,
+                     e->word, e->pos, e->type, e->eln_w, e->eln_b, c.layer_norm_eps, e->x, e->d_flag);
+  const uint32_t dh = c.hidden / c.heads;
+  for (const auto& ly : e->layers) {
+    launch_gemm<0, false>(e->x, ly.wqkv, ly.bqkv, nullptr, e->qkv, M, 3 * h, h, st);
+    dim3 ag((uint32_t)(B * c.heads), (uint32_t)((L + 63) / 64));
+    if (dh == 64) hipLaunchKernelGGL(attention_kernel<64>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
+    else if (dh == 32) hipLaunchKernelGGL(attention_kernel<32>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
+    else hipLaunchKernelGGL(attention_kernel<16>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
+    launch_gemm<0, true>(e->ctx, ly.wo, ly.bo, e->x, e->t, M, h, h, st);
+    hipLaunchKernelGGL(ln_kernel, dim3((uint32_t)M), dim3(64), h * 4, st, e->t, (uint32_t)h, ly.ln1w, ly.ln1b, c.layer_norm_eps, e->x1);
+    if (c.gelu_tanh) launch_gemm<2, false>(e->x1, ly.wi, ly.bi, nullptr, e->inter, M, I, h, st);
+    else launch_gemm<1, false>(e->x1, ly.wi, ly.bi, nullptr, e->inter, M, I, h, st);
+    launch_gemm<0, true>(e->inter, ly.wo2, ly.bo2, e->x1, e->t, M, h, I, st);
+    hipLaunchKernelGGL(ln_kernel, dim3((uint32_t)M), dim3(64), h * 4, st, e->t, (uint32_t)h, ly.ln2w, ly.ln2b, c.layer_norm_eps, e->x);
+  }
+  ISL_HIP(hipGetLastError());
+  return ISL_OK;
+}
+
+isl_status check_ids_flag(isl_encoder* e, hipStream_t st) {
+  uint32_t flag = 0;
+  ISL_HIP(hipMemcpyAsync(&flag, e->d_flag, 4, hipMemcpyDeviceToHost, st));
+  ISL_HIP(hipStreamSynchronize(st));
+  if (flag) return isl::fail(ISL_ERR_EMBEDDING, "Embedding error: token or token-type id out of range");
+  return ISL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void isl_encoder_free(isl_encoder* e) {
+  if (!e) return;
+  if (e->device >= 0) {
+    (void)hipSetDevice(e->device);
+    for (void* p : e->owned) (void)hipFree(p);
+    void* ws[] = {e->x, e->x1, e->t, e->qkv, e->ctx, e->inter, e->d_mask, e->d_ids, e->d_tt, e->d_flag};
+    for (void* p : ws)
+      if (p) (void)hipFree(p);
+  }
+  delete e;
+}
+
+isl_status isl_encoder_new(const isl_bert_config* cfg, int32_t device, isl_encoder** out) {
+  if (!cfg || !out) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL argument");
+  const isl_bert_config& c = *cfg;
+  if (!c.vocab_size || !c.hidden || !c.layers || !c.heads || !c.intermediate || !c.max_position || !c.type_vocab)
+    return isl::fail(ISL_ERR_INVALID_CONFIG, "Invalid configuration: zero-sized encoder dimension");
+  if (c.hidden % c.heads)
+    return isl::fail(ISL_ERR_INVALID_CONFIG, "Invalid configuration: hidden must be a multiple of heads");
+  const uint32_t dh = c.hidden / c.heads;
+  if (dh != 16 && dh != 32 && dh != 64)
+    return isl::fail(ISL_ERR_UNSUPPORTED, "head size %u is not built (16, 32 and 64 are)", dh);
+  if (c.hidden % 4 || c.intermediate % 4)
+    return isl::fail(ISL_ERR_UNSUPPORTED, "hidden and intermediate sizes must be multiples of 4");
+  ISL_TRY(isl::use_device(device));
+  isl_encoder* e = new isl_encoder();
+  e->cfg = c;
+  e->device = device;
+  bool ok = true;
+  auto alloc = [&](uint64_t n) -> float* {
+    void* p = nullptr;
+    if (hipMalloc(&p, n * 4) != hipSuccess || hipMemset(p, 0, n * 4) != hipSuccess) { ok = false; return nullptr; }
+    e->owned.push_back(p);
+    return (float*)p;
+  };
+  const uint64_t h = c.hidden, I = c.intermediate;
+  e->word = alloc((uint64_t)c.vocab_size * h);
+  e->pos = alloc((uint64_t)c.max_position * h);
+  e->type = alloc((uint64_t)c.type_vocab * h);
+  e->eln_w = alloc(h);
+  e->eln_b = alloc(h);
+  e->layers.resize(c.layers);
+  for (auto& ly : e->layers) {
+    ly.wqkv = alloc(3 * h * h); ly.bqkv = alloc(3 * h);
+    ly.wo = alloc(h * h); ly.bo = alloc(h);
+    ly.ln1w = alloc(h); ly.ln1b = alloc(h);
+    ly.wi = alloc(I * h); ly.bi = alloc(I);
+    ly.wo2 = alloc(h * I); ly.bo2 = alloc(h);
+    ly.ln2w = alloc(h); ly.ln2b = alloc(h);
+  }
+  if (ok && hipMalloc(&e->d_flag, 4) != hipSuccess) ok = false;
+  if (!ok) {
+    isl_encoder_free(e);
+    return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed for the encoder weights");
+  }
+  *out = e;
+  return ISL_OK;
+}
+
+// Tensor names as in the HuggingFace checkpoint candle's VarBuilder reads
+// (candle_provider.rs:267-284), with or without the "bert." prefix.
+isl_status isl_encoder_set_weight(isl_encoder* e, const char* name, const float* data, uint64_t count,
+                                  int32_t mem) {
+  if (!e || !name || !data) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL argument");
+  ISL_TRY(isl::use_device(e->device));
+  std::string n(name);
+  if (n.rfind("bert.", 0) == 0) n = n.substr(5);
+  const uint64_t h = e->cfg.hidden, I = e->cfg.intermediate;
+  float* dst = nullptr;
+  uint64_t want = 0;
+  if (n == "embeddings.word_embeddings.weight") { dst = e->word; want = (uint64_t)e->cfg.vocab_size * h; }
+  else if (n == "embeddings.position_embeddings.weight") { dst = e->pos; want = (uint64_t)e->cfg.max_position * h; }
+  else if (n == "embeddings.token_type_embeddings.weight") { dst = e->type; want = (uint64_t)e->cfg.type_vocab * h; }
+  else if (n == "embeddings.LayerNorm.weight") { dst = e->eln_w; want = h; }
+  else if (n == "embeddings.LayerNorm.bias") { dst = e->eln_b; want = h; }
+  else if (n.rfind("encoder.layer.", 0) == 0) {
+    size_t dot = n.find('.', 14);
+    if (dot == std::string::npos) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "unknown tensor %s", name);
+    uint64_t li = strtoull(n.substr(14, dot - 14).c_str(), nullptr, 10);
+    if (li >= e->layers.size()) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "layer index out of range in %s", name);
+    auto& ly = e->layers[li];
+    std::string r = n.substr(dot + 1);
+    if (r == "attention.self.query.weight") { dst = ly.wqkv; want = h * h; }
+    else if (r == "attention.self.key.weight") { dst = ly.wqkv + h * h; want = h * h; }
+    else if (r == "attention.self.value.weight") { dst = ly.wqkv + 2 * h * h; want = h * h; }
+    else if (r == "attention.self.query.bias") { dst = ly.bqkv; want = h; }
+    else if (r == "attention.self.key.bias") { dst = ly.bqkv + h; want = h; }
+    else if (r == "attention.self.value.bias") { dst = ly.bqkv + 2 * h; want = h; }
+    else if (r == "attention.output.dense.weight") { dst = ly.wo; want = h * h; }
+    else if (r == "attention.output.dense.bias") { dst = ly.bo; want = h; }
+    else if (r == "attention.output.LayerNorm.weight") { dst = ly.ln1w; want = h; }
+    else if (r == "attention.output.LayerNorm.bias") { dst = ly.ln1b; want = h; }
+    else if (r == "intermediate.dense.weight") { dst = ly.wi; want = I * h; }
+    else if (r == "intermediate.dense.bias") { dst = ly.bi; want = I; }
+    else if (r == "output.dense.weight") { dst = ly.wo2; want = h * I; }
+    else if (r == "output.dense.bias") { dst = ly.bo2; want = h; }
+    else if (r == "output.LayerNorm.weight") { dst = ly.ln2w; want = h; }
+    else if (r == "output.LayerNorm.bias") { dst = ly.ln2b; want = h; }
+  }
+  if (!dst) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "unknown tensor %s", name);
+  if (count != want) {
+    return isl::fail_dim(want, count);
+  }
+  ISL_HIP(hipMemcpy(dst, data, count * 4, mem == ISL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice));
+  return ISL_OK;
+}
+
+isl_status isl_encoder_forward(isl_encoder* e, const int64_t* input_ids, const int64_t* token_type_ids,
+                               const float* attention_mask, uint64_t B, uint64_t L, float* out_hidden,
+                               int32_t mem, void* stream) {
+  if (!e || !input_ids || !out_hidden) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (B == 0 || L == 0) return ISL_OK;
+  ISL_TRY(isl::use_device(e->device));
+  std::lock_guard<std::mutex> lock(e->mu);
+  hipStream_t st = (hipStream_t)stream;
+  ISL_TRY(run_forward(e, input_ids, token_type_ids, attention_mask, B, L, mem, st));
+  ISL_HIP(hipMemcpyAsync(out_hidden, e->x, B * L * e->cfg.hidden * 4,
+                         mem == ISL_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+  return check_ids_flag(e, st);
+}
+
+isl_status isl_encoder_embed(isl_encoder* e, const int64_t* input_ids, const int64_t* token_type_ids,
+                             const float* attention_mask, uint64_t B, uint64_t L, int32_t normalize,
+                             float* out, int32_t mem, void* stream) {
+  if (!e || !input_ids || !out) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (B == 0) return ISL_OK;  // embed_texts_raw(&[]) -> Ok(vec![]), candle_provider.rs:354-356
+  if (L == 0) return isl::fail(ISL_ERR_EMBEDDING, "Embedding error: empty sequences");
+  ISL_TRY(isl::use_device(e->device));
+  std::lock_guard<std::mutex> lock(e->mu);
+  hipStream_t st = (hipStream_t)stream;
+  ISL_TRY(run_forward(e, input_ids, token_type_ids, attention_mask, B, L, mem, st));
+  const uint64_t h = e->cfg.hidden;
+  float* d_out = out;
+  if (mem == ISL_MEM_HOST) d_out = e->t;  // B*h <= tokens*h
+  hipLaunchKernelGGL(pool_kernel, dim3((uint32_t)B), dim3(64), 0, st, e->x, e->d_mask, (uint32_t)L, (uint32_t)h,
+                     normalize, d_out);
+  ISL_HIP(hipGetLastError());
+  if (mem == ISL_MEM_HOST) ISL_HIP(hipMemcpyAsync(out, d_out, B * h * 4, hipMemcpyDeviceToHost, st));
+  return check_ids_flag(e, st);
+}
+
+}  // extern "C"

@@ -18,7 +18,10 @@ __global__ void merge_topk_kernel(uint32_t nlists, uint32_t nq, uint32_t k,
                                   const uint64_t* __restrict__ id_base, uint32_t top_k,
                                   uint64_t* __restrict__ out_ids, float* __restrict__ out_scores,
                                   uint32_t* __restrict__ out_src, uint32_t* __restrict__ out_count,
-                                  uint32_t* __restrict__ flags) {
+                                  uint32_t* __restrict__ flags, uint32_t service) {
+  // service != 0: the product-level merge of src/indexer/service.rs:787-801 -- results whose id
+  // has no file entry are dropped (`id_base` then holds files.len() per list), score =
+  // 1.0 - distance, stable sort by score DESCENDING, truncate.
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
   constexpr uint32_t MAXL = 64;
@@ -45,16 +48,19 @@ __global__ void merge_topk_kernel(uint32_t nlists, uint32_t nq, uint32_t k,
     for (uint32_t l = 0; l < nlists; ++l) {
       uint32_t c = counts[(uint64_t)l * nq + q];
       if (c > k) c = k;
+      if (service && id_base)  // stored.files.get(id) == None -> skipped, service.rs:788
+        while (pos[l] < c && ids[((uint64_t)l * nq + q) * k + pos[l]] >= id_base[l]) pos[l]++;
       if (pos[l] >= c) continue;
       float s = scores[((uint64_t)l * nq + q) * k + pos[l]];
-      if (best < 0 || s < bs) {  // strict: equal scores keep the earlier list
+      if (service) s = 1.0f - s;  // service.rs:791
+      if (best < 0 || (service ? s > bs : s < bs)) {  // strict: equal scores keep the earlier list
         best = (int)l;
         bs = s;
       }
     }
     if (best < 0) break;
     uint64_t src = ((uint64_t)best * nq + q) * k + pos[best];
-    out_ids[(uint64_t)q * top_k + n] = ids[src] + (id_base ? id_base[best] : 0ull);
+    out_ids[(uint64_t)q * top_k + n] = ids[src] + ((id_base && !service) ? id_base[best] : 0ull);
     out_scores[(uint64_t)q * top_k + n] = bs;
     if (out_src) out_src[(uint64_t)q * top_k + n] = (uint32_t)best;
     pos[best]++;
@@ -65,11 +71,11 @@ __global__ void merge_topk_kernel(uint32_t nlists, uint32_t nq, uint32_t k,
 
 }  // namespace
 
-extern "C" isl_status isl_merge_topk(uint64_t nlists, uint64_t nq, uint64_t k, const uint64_t* ids,
-                                     const float* scores, const uint32_t* counts,
-                                     const uint64_t* id_base, uint64_t top_k, uint64_t* out_ids,
-                                     float* out_scores, uint32_t* out_src, uint32_t* out_count,
-                                     int32_t mem, int32_t device, void* stream) {
+static isl_status merge_lists(uint32_t service, uint64_t nlists, uint64_t nq, uint64_t k,
+                              const uint64_t* ids, const float* scores, const uint32_t* counts,
+                              const uint64_t* id_base, uint64_t top_k, uint64_t* out_ids,
+                              float* out_scores, uint32_t* out_src, uint32_t* out_count,
+                              int32_t mem, int32_t device, void* stream) {
   if (nq == 0) return ISL_OK;
   if (nlists == 0 || nlists > 64)
     return isl::fail(ISL_ERR_INVALID_ARGUMENT, "nlists must be in [1, 64]");
@@ -121,7 +127,7 @@ extern "C" isl_status isl_merge_topk(uint64_t nlists, uint64_t nq, uint64_t k, c
     uint32_t blocks = (uint32_t)((nq + 63) / 64);
     hipLaunchKernelGGL(merge_topk_kernel, dim3(blocks), dim3(64), 0, st, (uint32_t)nlists,
                        (uint32_t)nq, (uint32_t)k, d_ids, d_sc, d_cnt, d_base, (uint32_t)top_k, d_oi,
-                       d_os, d_osrc, d_oc, d_flags);
+                       d_os, d_osrc, d_oc, d_flags, service);
     e = hipGetLastError();
   }
   uint32_t flags = 0;
@@ -138,10 +144,30 @@ extern "C" isl_status isl_merge_topk(uint64_t nlists, uint64_t nq, uint64_t k, c
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   cleanup();
   if (e != hipSuccess)
-    return isl::fail(ISL_ERR_DEVICE, "isl_merge_topk failed: %s", hipGetErrorString(e));
+    return isl::fail(ISL_ERR_DEVICE, "merge failed: %s", hipGetErrorString(e));
   if (flags & 1u)
-    return isl::fail(ISL_ERR_SEARCH, "Search error: NaN score in merge (the reference panics here)");
+    return isl::fail(ISL_ERR_SEARCH, service
+                         ? "Search error: NaN distance in the service merge (order undefined in the reference)"
+                         : "Search error: NaN score in merge (the reference panics here)");
   if (flags & 2u)
     return isl::fail(ISL_ERR_INVALID_ARGUMENT, "per-list scores must be ascending");
   return ISL_OK;
+}
+
+extern "C" isl_status isl_merge_topk(uint64_t nlists, uint64_t nq, uint64_t k, const uint64_t* ids,
+                                     const float* scores, const uint32_t* counts,
+                                     const uint64_t* id_base, uint64_t top_k, uint64_t* out_ids,
+                                     float* out_scores, uint32_t* out_src, uint32_t* out_count,
+                                     int32_t mem, int32_t device, void* stream) {
+  return merge_lists(0, nlists, nq, k, ids, scores, counts, id_base, top_k, out_ids, out_scores,
+                     out_src, out_count, mem, device, stream);
+}
+
+extern "C" isl_status isl_merge_service(uint64_t nlists, uint64_t nq, uint64_t k, const uint64_t* ids,
+                                        const float* distances, const uint32_t* counts,
+                                        const uint64_t* files_len, uint64_t top_k, uint64_t* out_ids,
+                                        float* out_scores, uint32_t* out_src, uint32_t* out_count,
+                                        int32_t mem, int32_t device, void* stream) {
+  return merge_lists(1, nlists, nq, k, ids, distances, counts, files_len, top_k, out_ids, out_scores,
+                     out_src, out_count, mem, device, stream);
 }

@@ -144,6 +144,33 @@ def test_multi_index_searcher(orc):  # search.rs:402-430, 211-237
     assert ia.MultiIndexSearcher().search(q) == []
 
 
+def test_merge_service_matches_oracle(orc):  # indexer/service.rs:787-801
+    rng = np.random.default_rng(8)
+    nl, nq, k = 3, 11, 7
+    dist = np.sort(rng.integers(0, 6, (nl, nq, k)).astype(np.float32) / 8, axis=2)
+    dist[0, 0, :3] = [1e-9, 2e-9, 3e-9]  # different distances, equal scores after 1 - d
+    ids = rng.integers(0, 50, (nl, nq, k)).astype(np.uint64)
+    counts = rng.integers(0, k + 1, (nl, nq)).astype(np.uint32)
+    counts[0, 0] = k
+    files_len = np.array([50, 30, 40], np.uint64)
+    for fl in (None, files_len):
+        oi, osc, osrc, oc = ia.merge_service(ids, dist, counts, 5, files_len=fl)
+        for q in range(nq):
+            li, ld = [], []
+            for l in range(nl):
+                a, b = ids[l, q, :counts[l, q]], dist[l, q, :counts[l, q]]
+                if fl is not None:
+                    keep = a < fl[l]
+                    a, b = a[keep], b[keep]
+                li.append(a)
+                ld.append(b)
+            st, ei, es, esrc = orc.service_merge(li, ld, 5)
+            n = int(oc[q])
+            assert st == 0 and n == ei.size
+            assert oi[q, :n].tolist() == ei.tolist() and osrc[q, :n].tolist() == esrc.tolist()
+            assert bits(osc[q, :n]).tolist() == bits(es).tolist()
+
+
 # --------------------------------------------------- embedding/candle_provider.rs
 @pytest.mark.parametrize("B,L,H", [(1, 1, 8), (3, 17, 384), (5, 128, 768), (2, 512, 64)])
 def test_mean_pool_normalize_matches_oracle(orc, B, L, H):
