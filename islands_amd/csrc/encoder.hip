@@ -108,10 +108,10 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 
 // C[M,N] = A[M,K] W[N,K]^T + bias (+ R) with an optional GELU: Linear layers of the encoder.
 // 128x128 tile per 256-thread workgroup, 64x64 per wave = 2x2 MFMA 32x32 blocks, K in slabs of
-// 16 staged k-major in LDS (the next slab is fetched into registers while the current one feeds
+// 32 staged k-major in LDS (the next slab is fetched into registers while the current one feeds
 // the matrix cores).  v_mfma_f32_32x32x2_f32: lane l supplies A[l%32][l/32] and B[l/32][l%32],
 // accumulator register r of lane l is C[8*(r/4) + 4*(l/32) + r%4][l%32].
-constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 4;
+constexpr int BM = 128, BN = 128, BK = 32, LDT = BM + 4;
 template <int ACT, bool RES>
 __global__ __launch_bounds__(256) void gemm_tn_f32(const float* __restrict__ A,
                                                    const float* __restrict__ W,
@@ -130,22 +130,51 @@ __global__ __launch_bounds__(256) void gemm_tn_f32(const float* __restrict__ A,
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  // this thread's two float4 of the A slab and of the W slab: row = idx / 4, k-quad = idx % 4
-  const uint32_t r0 = tid >> 2, r1 = (tid + 256) >> 2, kq = (tid & 3) * 4;
-  float4 pa0, pa1, pb0, pb1;
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  // A slab and W slab are 128 rows x 32 floats = 1024 float4 each: thread t owns float4 number
+  // t, t+256, t+512, t+768 -> row = idx / 8, k-octet = idx % 8.  Rows / columns past the matrix
+  // are clamped to the last valid one (the loads stay unconditional 16-byte loads) and zeroed
+  // after the load on edge tiles only.
+  const uint32_t kq = (tid & 7) * 4;
+  uint32_t ra[4], rb[4];
+  bool za[4], zb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t r = (tid + 256u * i) >> 3;
+    za[i] = m0 + r >= M;
+    zb[i] = n0 + r >= N;
+    ra[i] = (uint32_t)(za[i] ? M - 1 - m0 : r);
+    rb[i] = (uint32_t)(zb[i] ? N - 1 - n0 : r);
+  }
+  const bool edge = m0 + BM > M || n0 + BN > N || (K % BK) != 0;
+  const float* Ab = A + m0 * K + kq;
+  const float* Wb = W + n0 * K + kq;
+  float4 pa[4], pb[4];
   auto fetch = [&](uint32_t k0) {
-    const bool kin = k0 + kq < K;  // K is a multiple of 4 (checked on the host)
-    pa0 = (kin && m0 + r0 < M) ? *reinterpret_cast<const float4*>(A + (m0 + r0) * K + k0 + kq) : zero;
-    pa1 = (kin && m0 + r1 < M) ? *reinterpret_cast<const float4*>(A + (m0 + r1) * K + k0 + kq) : zero;
-    pb0 = (kin && n0 + r0 < N) ? *reinterpret_cast<const float4*>(W + (n0 + r0) * K + k0 + kq) : zero;
-    pb1 = (kin && n0 + r1 < N) ? *reinterpret_cast<const float4*>(W + (n0 + r1) * K + k0 + kq) : zero;
+    if (!edge) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        pa[i] = *reinterpret_cast<const float4*>(Ab + (uint64_t)ra[i] * K + k0);
+        pb[i] = *reinterpret_cast<const float4*>(Wb + (uint64_t)rb[i] * K + k0);
+      }
+    } else {
+      const bool kout = k0 + kq >= K;  // K is a multiple of 4 (checked on the host)
+      const uint32_t kc = kout ? 0u : k0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        pa[i] = *reinterpret_cast<const float4*>(Ab + (uint64_t)ra[i] * K + kc);
+        pb[i] = *reinterpret_cast<const float4*>(Wb + (uint64_t)rb[i] * K + kc);
+        if (kout || za[i]) pa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kout || zb[i]) pb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
   };
   auto stage = [&]() {
-    As[kq + 0][r0] = pa0.x; As[kq + 1][r0] = pa0.y; As[kq + 2][r0] = pa0.z; As[kq + 3][r0] = pa0.w;
-    As[kq + 0][r1] = pa1.x; As[kq + 1][r1] = pa1.y; As[kq + 2][r1] = pa1.z; As[kq + 3][r1] = pa1.w;
-    Bs[kq + 0][r0] = pb0.x; Bs[kq + 1][r0] = pb0.y; Bs[kq + 2][r0] = pb0.z; Bs[kq + 3][r0] = pb0.w;
-    Bs[kq + 0][r1] = pb1.x; Bs[kq + 1][r1] = pb1.y; Bs[kq + 2][r1] = pb1.z; Bs[kq + 3][r1] = pb1.w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t r = (tid + 256u * i) >> 3;
+      As[kq + 0][r] = pa[i].x; As[kq + 1][r] = pa[i].y; As[kq + 2][r] = pa[i].z; As[kq + 3][r] = pa[i].w;
+      Bs[kq + 0][r] = pb[i].x; Bs[kq + 1][r] = pb[i].y; Bs[kq + 2][r] = pb[i].z; Bs[kq + 3][r] = pb[i].w;
+    }
   };
   fetch(0);
   const uint32_t kh = lane >> 5, c32 = lane & 31;
