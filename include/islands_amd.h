@@ -189,6 +189,8 @@ typedef struct isl_search_stats {
   uint64_t exact_path;     /* queries answered by the heap-exact kernel */
   uint64_t replayed;       /* queries whose tied prefix was re-ordered by the replay kernel */
   double kernel_ms;        /* HIP-event time of the search kernels of that call */
+  uint64_t encoded_nodes;    /* recompute provider: embeddings computed by the encoder */
+  uint64_t recompute_rounds; /* recompute provider: search rounds of that call (0 otherwise) */
 } isl_search_stats;
 isl_status isl_search_last_stats(const isl_index* idx, isl_search_stats* out);
 
@@ -286,6 +288,20 @@ isl_status isl_encoder_forward(isl_encoder* enc, const int64_t* input_ids,
 isl_status isl_encoder_embed(isl_encoder* enc, const int64_t* input_ids, const int64_t* token_type_ids,
                              const float* attention_mask, uint64_t B, uint64_t L, int32_t normalize,
                              float* out, int32_t mem, void* stream);
+
+/* Recompute provider: EmbeddingProvider (leann.rs:82-99) backed by the encoder, the mode the
+ * paper and `LeannConfig::is_recompute` (leann.rs:366-371) describe -- no stored embeddings, the
+ * vectors of the nodes a search visits are computed on the fly from their text.  `tokens` holds
+ * node i's tokenised text in row i (n rows of L slots, `lengths[i]` of them used, NULL = all L;
+ * tokenisation itself is third-party code outside this library).  After the call searches on
+ * `idx` re-encode what they visit: the rows a batch misses are encoded once each, in batches
+ * across all its queries.  keep_rows = 0 forgets every row when a call returns (pure recompute),
+ * 1 keeps them as an embedding cache.  The encoder is borrowed and must outlive the index;
+ * its hidden size becomes the index dimension; `normalize` as in isl_encoder_embed.
+ * Results equal those of the in-memory provider holding the same embeddings. */
+isl_status isl_set_recompute_provider(isl_index* idx, isl_encoder* enc, const uint16_t* tokens,
+                                      const uint16_t* lengths, uint64_t n, uint64_t L,
+                                      int32_t normalize, int32_t keep_rows, int32_t mem);
 
 /* ---- embedding/candle_provider.rs:434-488: masked mean-pool + optional L2 normalise ----
  * hidden [B][L][H] f32, mask [B][L] (0/1 as f32), out [B][H].  The BERT forward that

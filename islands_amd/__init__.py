@@ -351,6 +351,19 @@ class LeannIndex:
         _check(_ffi.lib().isl_index_upload(self._h, device))
         return self
 
+    def set_recompute_provider(self, embedder: "CandleEmbedder", tokens, lengths=None,
+                               keep_rows: bool = False) -> "LeannIndex":
+        """EmbeddingProvider backed by the encoder (recompute mode, leann.rs:82-99): `tokens`
+        [n, L] uint16 holds node i's tokenised text in row i, `lengths[i]` slots of it used."""
+        t = np.ascontiguousarray(tokens, dtype=np.uint16)
+        ln = None if lengths is None else np.ascontiguousarray(lengths, dtype=np.uint16)
+        n, L = t.shape
+        _check(_ffi.lib().isl_set_recompute_provider(
+            self._h, embedder._h, _ptr(t), None if ln is None else _ptr(ln), n, L,
+            int(embedder.normalize), int(keep_rows), MEM_HOST))
+        self._embedder = embedder  # borrowed by the library: keep it alive
+        return self
+
     def set_embeddings(self, rows, device_ptr: int | None = None, n: int | None = None,
                        d: int | None = None) -> "LeannIndex":
         """Attach the in-memory provider (leann.rs:111-120).  Either a host matrix, or

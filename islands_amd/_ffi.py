@@ -40,7 +40,8 @@ class BertConfigC(C.Structure):
 
 class SearchStatsC(C.Structure):
     _fields_ = [("queries", u64), ("expansions", u64), ("edges", u64), ("evals", u64),
-                ("pushes", u64), ("exact_path", u64), ("replayed", u64), ("kernel_ms", C.c_double)]
+                ("pushes", u64), ("exact_path", u64), ("replayed", u64), ("kernel_ms", C.c_double),
+                ("encoded_nodes", u64), ("recompute_rounds", u64)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/islands_amd.h
@@ -104,6 +105,8 @@ SIGNATURES = {
                                   C.c_void_p, i32, C.c_void_p]),
     "isl_encoder_embed": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u64, u64, i32,
                                 C.c_void_p, i32, C.c_void_p]),
+    "isl_set_recompute_provider": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u64, u64,
+                                         i32, i32, i32]),
     "isl_mean_pool_normalize": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, i32, C.c_void_p, i32,
                                       i32, C.c_void_p]),
     "isl_hnsw_from_layers": (i32, [u64, u64, u64, i32, u64, u64, u64, C.c_void_p, C.c_void_p,

@@ -3,6 +3,7 @@
 // in-memory embedding provider.  Mirrors src/core/leann.rs of the reference;
 // each function cites the lines it replaces.
 #include "device_common.cuh"
+#include "encoder.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -67,6 +68,9 @@ void free_workspace(SearchWorkspace& ws) {
   if (ws.h_ctr) (void)hipHostFree(ws.h_ctr);
   if (ws.h_head) (void)hipHostFree(ws.h_head);
   if (ws.d_prof) (void)hipFree(ws.d_prof);
+  if (ws.miss) (void)hipFree(ws.miss);
+  if (ws.uniq) (void)hipFree(ws.uniq);
+  if (ws.uniq_count) (void)hipFree(ws.uniq_count);
   if (ws.ev0) (void)hipEventDestroy(ws.ev0);
   if (ws.ev1) (void)hipEventDestroy(ws.ev1);
   if (ws.ev_in) (void)hipEventDestroy(ws.ev_in);
@@ -247,6 +251,9 @@ void isl_index_free(isl_index* idx) {
   if (!idx) return;
   if (idx->device >= 0) {
     (void)hipSetDevice(idx->device);
+    if (idx->d_tokens) (void)hipFree(idx->d_tokens);
+    if (idx->d_lens) (void)hipFree(idx->d_lens);
+    if (idx->d_present) (void)hipFree(idx->d_present);
     if (idx->d_off) (void)hipFree(idx->d_off);
     if (idx->d_adj) (void)hipFree(idx->d_adj);
     if (idx->d_emb) (void)hipFree(idx->d_emb);
@@ -660,6 +667,7 @@ isl_status isl_set_embeddings(isl_index* idx, const void* rows, uint64_t n, uint
   ISL_TRY(use_device(idx->device));
   std::lock_guard<std::mutex> lock(idx->mu);
   if (idx->d_emb) { (void)hipFree(idx->d_emb); idx->d_emb = nullptr; }
+  idx->recompute = false;  // back to the in-memory provider
   uint64_t stride = (d + 3) / 4 * 4;  // rows start 16-byte aligned
   size_t bytes = (size_t)(n * stride + 256) * sizeof(float);  // slack for whole-slab reads
   ISL_HIP(hipMalloc(&idx->d_emb, bytes));
@@ -684,6 +692,57 @@ isl_status isl_set_embeddings(isl_index* idx, const void* rows, uint64_t n, uint
     ISL_HIP(hipGetLastError());
     ISL_HIP(hipDeviceSynchronize());
   }
+  return ISL_OK;
+}
+
+// EmbeddingProvider backed by the encoder (recompute mode), see islands_amd.h.
+isl_status isl_set_recompute_provider(isl_index* idx, isl_encoder* enc, const uint16_t* tokens,
+                                      const uint16_t* lengths, uint64_t n, uint64_t L,
+                                      int32_t normalize, int32_t keep_rows, int32_t mem) {
+  if (!idx || !enc || (!tokens && n)) return fail(ISL_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (n == 0) return fail(ISL_ERR_EMPTY_COLLECTION, "Empty vector collection");
+  if (idx->device < 0) return fail(ISL_ERR_DEVICE, "call isl_index_upload before attaching a provider");
+  if (enc->device != idx->device) return fail(ISL_ERR_INVALID_ARGUMENT, "encoder and index live on different devices");
+  if (idx->is_hnsw) return fail(ISL_ERR_UNSUPPORTED, "the HnswGraph facade stores its vectors (hnsw.rs:97-112)");
+  if (L == 0 || L > enc->cfg.max_position)
+    return fail(ISL_ERR_EMBEDDING, "Embedding error: %llu token slots per node, the model takes 1..%u",
+                (unsigned long long)L, enc->cfg.max_position);
+  if (n > 0x7FFFFFF0ull) return fail(ISL_ERR_UNSUPPORTED, "node ids above the device id range");
+  ISL_TRY(use_device(idx->device));
+  std::lock_guard<std::mutex> lock(idx->mu);
+  const uint64_t d = enc->cfg.hidden, stride = (d + 3) / 4 * 4;
+  void* olds[] = {idx->d_emb, idx->d_norm2, idx->d_tokens, idx->d_lens, idx->d_present};
+  for (void* p : olds)
+    if (p) (void)hipFree(p);
+  idx->d_emb = nullptr; idx->d_norm2 = nullptr; idx->d_tokens = nullptr; idx->d_lens = nullptr;
+  idx->d_present = nullptr;
+  idx->recompute = false;
+  // the row table is addressed by node id like the in-memory provider's; rows are valid only
+  // where d_present says so (288 GB of HBM make a dense table the simplest cache)
+  ISL_HIP(hipMalloc(&idx->d_emb, (size_t)(n * stride + 256) * sizeof(float)));
+  ISL_HIP(hipMemset(idx->d_emb, 0, (size_t)(n * stride + 256) * sizeof(float)));
+  ISL_HIP(hipMalloc(&idx->d_norm2, (size_t)n * 4));
+  ISL_HIP(hipMemset(idx->d_norm2, 0, (size_t)n * 4));
+  idx->present_words = (n + 31) / 32 + 1;
+  ISL_HIP(hipMalloc(&idx->d_present, idx->present_words * 4));
+  ISL_HIP(hipMemset(idx->d_present, 0, idx->present_words * 4));
+  hipMemcpyKind kind = mem == ISL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  ISL_HIP(hipMalloc(&idx->d_tokens, (size_t)n * L * 2));
+  ISL_HIP(hipMemcpy(idx->d_tokens, tokens, (size_t)n * L * 2, kind));
+  if (lengths) {
+    ISL_HIP(hipMalloc(&idx->d_lens, (size_t)n * 2));
+    ISL_HIP(hipMemcpy(idx->d_lens, lengths, (size_t)n * 2, kind));
+  }
+  idx->enc = enc;
+  idx->tok_L = (uint32_t)L;
+  idx->nvec = n;
+  idx->emb_d = d;
+  idx->emb_stride = stride;
+  idx->enc_normalize = normalize;
+  idx->keep_rows = keep_rows != 0;
+  idx->recompute = true;
+  idx->cfg.is_recompute = 1;
+  if (!idx->has_dimension) { idx->has_dimension = true; idx->dimension = d; }
   return ISL_OK;
 }
 

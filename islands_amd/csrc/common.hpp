@@ -86,6 +86,11 @@ struct SearchWorkspace {
   uint32_t* h_head = nullptr;
   uint64_t h_cap = 0;
   uint64_t* d_prof = nullptr;    // ISL_DEBUG phase timers of the call in flight
+  // recompute provider: node ids whose rows a search round found absent, and their unique set
+  uint32_t* miss = nullptr;
+  uint32_t* uniq = nullptr;
+  uint32_t* uniq_count = nullptr;
+  uint64_t miss_cap = 0;
 };
 
 constexpr int kSearchLanes = 16;  // independent workspaces = searches that may be in flight
@@ -118,6 +123,18 @@ struct isl_index {
   float* d_emb = nullptr;
   float* d_norm2 = nullptr;  // [nvec] sum of squares of every row, reference summation order
   uint64_t nvec = 0, emb_d = 0, emb_stride = 0;
+
+  // recompute provider (EmbeddingProvider backed by the encoder, leann.rs:82-99): rows of d_emb
+  // exist only where d_present has a bit; the search reports the rows it misses and the
+  // provider encodes them from the resident token table
+  struct isl_encoder* enc = nullptr;   // borrowed
+  uint16_t* d_tokens = nullptr;        // [nvec][tok_L]
+  uint16_t* d_lens = nullptr;          // [nvec] or NULL
+  uint32_t tok_L = 0;
+  uint32_t* d_present = nullptr;       // bitmap over node ids
+  uint64_t present_words = 0;
+  bool recompute = false, keep_rows = false;
+  int32_t enc_normalize = 1;
 
   // HnswGraph facade (hnsw.rs): distance-only heap order + upper layers for the greedy descent
   bool is_hnsw = false;

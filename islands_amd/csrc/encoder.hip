@@ -13,31 +13,13 @@
 // gather are VALU kernels.  Every output row depends on its own sequence only and is reduced in a
 // fixed order, so a node's embedding does not depend on what it is batched with.
 #include "common.hpp"
+#include "encoder.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
-
-struct isl_encoder {
-  isl_bert_config cfg{};
-  int device = -1;
-  float *word = nullptr, *pos = nullptr, *type = nullptr, *eln_w = nullptr, *eln_b = nullptr;
-  struct Layer {
-    float *wqkv = nullptr, *bqkv = nullptr, *wo = nullptr, *bo = nullptr, *ln1w = nullptr,
-          *ln1b = nullptr, *wi = nullptr, *bi = nullptr, *wo2 = nullptr, *bo2 = nullptr,
-          *ln2w = nullptr, *ln2b = nullptr;
-  };
-  std::vector<Layer> layers;
-  std::vector<void*> owned;
-  // workspace, grown on demand (tokens = sequences * padded length)
-  uint64_t ws_tokens = 0;
-  float *x = nullptr, *x1 = nullptr, *t = nullptr, *qkv = nullptr, *ctx = nullptr, *inter = nullptr;
-  float* d_mask = nullptr;
-  int64_t *d_ids = nullptr, *d_tt = nullptr;
-  uint32_t* d_flag = nullptr;
-  std::mutex mu;
-};
 
 namespace {
 
@@ -298,8 +280,10 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__
 // sequence, lane j owns hidden units j, j+64, ...; sequential over the tokens.
 __global__ __launch_bounds__(64) void pool_kernel(const float* __restrict__ hid,
                                                   const float* __restrict__ mask, uint32_t L,
-                                                  uint32_t h, int normalize, float* __restrict__ out) {
+                                                  uint32_t h, int normalize, float* __restrict__ out_base,
+                                                  const uint32_t* __restrict__ out_rows, uint64_t out_stride) {
   const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  float* out = out_base + (uint64_t)(out_rows ? out_rows[b] : b) * out_stride;
   float sm = 0.0f;
   for (uint32_t t = 0; t < L; ++t) sm += mask[(uint64_t)b * L + t];
   if (sm < 1e-9f) sm = 1e-9f;
@@ -308,13 +292,13 @@ __global__ __launch_bounds__(64) void pool_kernel(const float* __restrict__ hid,
     float s = 0.0f;
     for (uint32_t t = 0; t < L; ++t) s += hid[((uint64_t)b * L + t) * h + j] * mask[(uint64_t)b * L + t];
     s = s / sm;
-    out[(uint64_t)b * h + j] = s;
+    out[j] = s;
     ss += s * s;
   }
   if (normalize) {
     float norm = sqrtf(wave_sum(ss));
     if (norm < 1e-12f) norm = 1e-12f;
-    for (uint32_t j = lane; j < h; j += 64) out[(uint64_t)b * h + j] = out[(uint64_t)b * h + j] / norm;
+    for (uint32_t j = lane; j < h; j += 64) out[j] = out[j] / norm;
   }
 }
 
@@ -352,23 +336,14 @@ __global__ void fill_f32(float* p, uint64_t n, float v) {
   if (i < n) p[i] = v;
 }
 
-// Runs the model on B sequences of padded length L; the last hidden state is left in e->x.
-isl_status run_forward(isl_encoder* e, const int64_t* ids, const int64_t* tt, const float* mask,
-                       uint64_t B, uint64_t L, int32_t mem, hipStream_t st) {
+// The model on B sequences of padded length L whose ids / types / mask already sit in the
+// workspace (e->d_ids, e->d_tt when has_tt, e->d_mask); the last hidden state is left in e->x.
+isl_status compute_forward(isl_encoder* e, bool has_tt, uint64_t B, uint64_t L, hipStream_t st) {
   const isl_bert_config& c = e->cfg;
-  if (L > c.max_position)
-    return isl::fail(ISL_ERR_EMBEDDING, "Embedding error: sequence length %llu exceeds max_position %u",
-                     (unsigned long long)L, c.max_position);
-  ISL_TRY(ensure_ws(e, B, L));
   const uint64_t M = B * L, h = c.hidden, I = c.intermediate;
-  hipMemcpyKind kind = mem == ISL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-  ISL_HIP(hipMemcpyAsync(e->d_ids, ids, M * 8, kind, st));
-  if (tt) ISL_HIP(hipMemcpyAsync(e->d_tt, tt, M * 8, kind, st));
-  if (mask) ISL_HIP(hipMemcpyAsync(e->d_mask, mask, M * 4, kind, st));
-  else hipLaunchKernelGGL(fill_f32, dim3((uint32_t)((M + 255) / 256)), dim3(256), 0, st, e->d_mask, M, 1.0f);
   ISL_HIP(hipMemsetAsync(e->d_flag, 0, 4, st));
   hipLaunchKernelGGL(embed_ln_kernel, dim3((uint32_t)M), dim3(64), h * 4, st, e->d_ids,
-                     tt ? e->d_tt : nullptr, (uint32_t)L, (uint32_t)h, c.vocab_size, c.type_vocab,
+                     has_tt ? e->d_tt : nullptr, (uint32_t)L, (uint32_t)h, c.vocab_size, c.type_vocab,
                      e->word, e->pos, e->type, e->eln_w, e->eln_b, c.layer_norm_eps, e->x, e->d_flag);
   const uint32_t dh = c.hidden / c.heads;
   for (const auto& ly : e->layers) {
@@ -388,6 +363,37 @@ isl_status run_forward(isl_encoder* e, const int64_t* ids, const int64_t* tt, co
   return ISL_OK;
 }
 
+// Uploads the inputs of B sequences of padded length L and runs the model.
+isl_status run_forward(isl_encoder* e, const int64_t* ids, const int64_t* tt, const float* mask,
+                       uint64_t B, uint64_t L, int32_t mem, hipStream_t st) {
+  if (L > e->cfg.max_position)
+    return isl::fail(ISL_ERR_EMBEDDING, "Embedding error: sequence length %llu exceeds max_position %u",
+                     (unsigned long long)L, e->cfg.max_position);
+  ISL_TRY(ensure_ws(e, B, L));
+  const uint64_t M = B * L;
+  hipMemcpyKind kind = mem == ISL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  ISL_HIP(hipMemcpyAsync(e->d_ids, ids, M * 8, kind, st));
+  if (tt) ISL_HIP(hipMemcpyAsync(e->d_tt, tt, M * 8, kind, st));
+  if (mask) ISL_HIP(hipMemcpyAsync(e->d_mask, mask, M * 4, kind, st));
+  else hipLaunchKernelGGL(fill_f32, dim3((uint32_t)((M + 255) / 256)), dim3(256), 0, st, e->d_mask, M, 1.0f);
+  return compute_forward(e, tt != nullptr, B, L, st);
+}
+
+// token table row -> the int64 ids / f32 mask the model kernels read
+__global__ void gather_tokens_kernel(const uint16_t* __restrict__ tokens, const uint16_t* __restrict__ lens,
+                                     uint32_t L, const uint32_t* __restrict__ node_ids, uint64_t n,
+                                     int64_t* __restrict__ ids, float* __restrict__ mask) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * L) return;
+  const uint64_t b = i / L;
+  const uint32_t t = (uint32_t)(i % L);
+  const uint32_t node = node_ids[b];
+  const uint32_t len = lens ? lens[node] : L;
+  const bool live = t < len;
+  ids[i] = live ? (int64_t)tokens[(uint64_t)node * L + t] : 0;  // padding id 0, candle_provider.rs:398
+  mask[i] = live ? 1.0f : 0.0f;
+}
+
 isl_status check_ids_flag(isl_encoder* e, hipStream_t st) {
   uint32_t flag = 0;
   ISL_HIP(hipMemcpyAsync(&flag, e->d_flag, 4, hipMemcpyDeviceToHost, st));
@@ -397,6 +403,31 @@ isl_status check_ids_flag(isl_encoder* e, hipStream_t st) {
 }
 
 }  // namespace
+
+namespace isl {
+isl_status encoder_embed_nodes(isl_encoder* e, const uint16_t* d_tokens, const uint16_t* d_lens,
+                               uint32_t L, const uint32_t* d_node_ids, uint64_t n, int normalize,
+                               float* d_rows, uint64_t stride, hipStream_t st) {
+  if (n == 0) return ISL_OK;
+  if (L == 0 || L > e->cfg.max_position)
+    return isl::fail(ISL_ERR_EMBEDDING, "Embedding error: token rows of %u slots do not fit max_position %u",
+                     L, e->cfg.max_position);
+  std::lock_guard<std::mutex> lock(e->mu);
+  const uint64_t chunk = 2048;  // sequences per model pass: (2048 x 64 tokens) x 3072 floats = 1.6 GB
+  ISL_TRY(ensure_ws(e, std::min(n, chunk), L));
+  for (uint64_t o = 0; o < n; o += chunk) {
+    const uint64_t B = std::min(chunk, n - o);
+    hipLaunchKernelGGL(gather_tokens_kernel, dim3((uint32_t)((B * L + 255) / 256)), dim3(256), 0, st, d_tokens,
+                       d_lens, L, d_node_ids + o, B, e->d_ids, e->d_mask);
+    ISL_TRY(compute_forward(e, false, B, L, st));
+    hipLaunchKernelGGL(pool_kernel, dim3((uint32_t)B), dim3(64), 0, st, e->x, e->d_mask, L,
+                       (uint32_t)e->cfg.hidden, normalize, d_rows, d_node_ids + o, stride);
+    ISL_HIP(hipGetLastError());
+    ISL_TRY(check_ids_flag(e, st));
+  }
+  return ISL_OK;
+}
+}  // namespace isl
 
 extern "C" {
 
@@ -535,7 +566,7 @@ isl_status isl_encoder_embed(isl_encoder* e, const int64_t* input_ids, const int
   float* d_out = out;
   if (mem == ISL_MEM_HOST) d_out = e->t;  // B*h <= tokens*h
   hipLaunchKernelGGL(pool_kernel, dim3((uint32_t)B), dim3(64), 0, st, e->x, e->d_mask, (uint32_t)L, (uint32_t)h,
-                     normalize, d_out);
+                     normalize, d_out, (const uint32_t*)nullptr, h);
   ISL_HIP(hipGetLastError());
   if (mem == ISL_MEM_HOST) ISL_HIP(hipMemcpyAsync(out, d_out, B * h * 4, hipMemcpyDeviceToHost, st));
   return check_ids_flag(e, st);

@@ -1,0 +1,36 @@
+// Internal view of the recompute encoder shared by encoder.hip (kernels, C ABI), api_index.hip
+// (isl_set_recompute_provider) and search.hip (the rounds that re-encode the nodes a search misses).
+#pragma once
+
+#include "common.hpp"
+
+struct isl_encoder {
+  isl_bert_config cfg{};
+  int device = -1;
+  float *word = nullptr, *pos = nullptr, *type = nullptr, *eln_w = nullptr, *eln_b = nullptr;
+  struct Layer {
+    float *wqkv = nullptr, *bqkv = nullptr, *wo = nullptr, *bo = nullptr, *ln1w = nullptr,
+          *ln1b = nullptr, *wi = nullptr, *bi = nullptr, *wo2 = nullptr, *bo2 = nullptr,
+          *ln2w = nullptr, *ln2b = nullptr;
+  };
+  std::vector<Layer> layers;
+  std::vector<void*> owned;
+  // workspace, grown on demand (tokens = sequences * padded length)
+  uint64_t ws_tokens = 0;
+  float *x = nullptr, *x1 = nullptr, *t = nullptr, *qkv = nullptr, *ctx = nullptr, *inter = nullptr;
+  float* d_mask = nullptr;
+  int64_t *d_ids = nullptr, *d_tt = nullptr;
+  uint32_t* d_flag = nullptr;
+  std::mutex mu;
+};
+
+
+namespace isl {
+// Encodes the nodes listed in d_node_ids (device) from the resident token table (u16 ids, row i
+// = node i, `L` slots per node, d_lens[i] of them used; NULL = all) and writes embedding b to
+// d_rows + d_node_ids[b] * stride.  Sequences are padded to L: masked keys contribute exact
+// zeros, so the result does not depend on the padded length.
+isl_status encoder_embed_nodes(isl_encoder* e, const uint16_t* d_tokens, const uint16_t* d_lens,
+                               uint32_t L, const uint32_t* d_node_ids, uint64_t n, int normalize,
+                               float* d_rows, uint64_t stride, hipStream_t st);
+}  // namespace isl

@@ -24,6 +24,7 @@
 //     (candidates in HBM scratch, results in LDS) for those queries, for
 //     ef > 512 and for adjacency rows longer than 64.
 #include "device_common.cuh"
+#include "encoder.hpp"
 
 #include <algorithm>
 #include <type_traits>
@@ -42,7 +43,8 @@ enum : uint32_t {
   QS_NODE_NOT_FOUND = 5,
   QS_REDO = 0x100,     // fast kernel gave up -> exact kernel
   QS_SCRATCH = 0x101,  // exact kernel ran out of candidate scratch
-  QS_REPLAY = 0x102    // result-heap order needed: replay kernel re-orders from the push log
+  QS_REPLAY = 0x102,   // result-heap order needed: replay kernel re-orders from the push log
+  QS_BLOCKED = 0x103   // recompute provider: a needed row is not materialised yet (ids reported)
 };
 
 struct SearchParams {
@@ -84,6 +86,11 @@ struct SearchParams {
   uint64_t vis_words;
   uint32_t* ulist;
   uint32_t ulist_cap;
+  // recompute provider: rows exist where `present` has a bit; a query that needs an absent row
+  // appends the id to `miss` (count in ticket[13]) and stops with QS_BLOCKED
+  const uint32_t* present;
+  uint32_t* miss;
+  uint32_t miss_cap;
   // HnswGraph facade (hnsw.rs): adjacency of the layers above 0 for the greedy descent
   const uint64_t* const* layer_off;  // [max_level + 1] device pointers (index 0 unused)
   const uint32_t* const* layer_adj;
@@ -386,6 +393,22 @@ __device__ void replay_result_order(const uint2* plog, uint32_t npush, uint32_t 
   __syncthreads();
 }
 
+// Recompute provider: true when every row of `uid` (lanes < n) is materialised; otherwise the
+// absent ids are appended to the miss list and the caller stops the query with QS_BLOCKED.
+__device__ __forceinline__ bool rows_present(const SearchParams& p, uint32_t uid, uint32_t n) {
+  if (!p.present) return true;
+  const uint32_t lane = threadIdx.x;
+  const bool absent = lane < n && !((p.present[uid >> 5] >> (uid & 31)) & 1u);
+  const uint64_t am = ballot(absent);
+  if (!am) return true;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(&p.ticket[13], (uint32_t)__popcll(am));
+  base = uni(base);
+  const uint32_t rank = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+  if (absent && base + rank < p.miss_cap) p.miss[base + rank] = uid;
+  return false;
+}
+
 // ------------------------------------------------------------------ fast kernel
 template <int S, int METRIC_API>
 __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
@@ -436,6 +459,8 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
     if ((uint64_t)p.entry >= p.nvec) {
       status = QS_NODE_NOT_FOUND;
       payload = p.entry;
+    } else if (!rows_present(p, p.entry, 1)) {
+      status = QS_BLOCKED;
     } else {
       float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[p.entry] : 0.0f;
       float ed = direct_distances<METRIC>(p.emb, p.stride, p.d, p.entry, 1, qs, q_norm, e_aux);
@@ -543,6 +568,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
         payload = rl_u(uid, bl);
         break;
       }
+      if (!rows_present(p, uid, keep)) { status = QS_BLOCKED; break; }
       cV += keep;
       ngroups += (keep + 15) / 16;
       nhops_rows += 1;
@@ -731,6 +757,8 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
     if ((uint64_t)p.entry >= p.nvec) {
       status = QS_NODE_NOT_FOUND;
       payload = p.entry;
+    } else if (!rows_present(p, p.entry, 1)) {
+      status = QS_BLOCKED;
     } else {
       uint32_t entry = p.entry;
       float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[entry] : 0.0f;
@@ -845,6 +873,15 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
         status = QS_NODE_NOT_FOUND;
         payload = first_bad;
         break;
+      }
+      if (p.present) {  // recompute provider: every kept row must be materialised
+        bool all_here = true;
+        for (uint32_t base = 0; base < keep; base += 64) {
+          const uint32_t R = keep - base < 64 ? keep - base : 64;
+          const uint32_t uid = (uint32_t)lane < R ? ulist[base + lane] : 0u;
+          if (!rows_present(p, uid, R)) all_here = false;
+        }
+        if (!all_here) { status = QS_BLOCKED; break; }
       }
       cV += keep;
       for (uint32_t base = 0; base < keep && status == QS_OK; base += 64) {
@@ -1187,6 +1224,9 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   p.vis_words = ws.vis_words;
   p.ulist = ws.ulist;
   p.ulist_cap = ws.ulist_cap;
+  p.present = idx->recompute ? idx->d_present : nullptr;
+  p.miss = ws.miss;
+  p.miss_cap = (uint32_t)std::min<uint64_t>(ws.miss_cap, 0xFFFFFFFFull);
   p.layer_off = idx->d_layer_off;
   p.layer_adj = idx->d_layer_adj;
   p.max_level = idx->is_hnsw ? (uint32_t)idx->max_level : 0u;
@@ -1242,7 +1282,7 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
 
 // Waits for the call in flight on `ws`, folds its counters into the index statistics and turns
 // per-query failures into the CoreError the reference's sequential map would have returned.
-isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws) {
+isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws, uint32_t* misses = nullptr) {
   if (!ws.busy) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "no search in flight for this token");
   ws.busy = false;
   const uint64_t nq = ws.nq_inflight;
@@ -1306,6 +1346,10 @@ isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws) {
             "NaN/-0 distance %u; %u re-ordered by the replay kernel\n", head[1], (unsigned long long)nq,
             use_fast ? "on" : "off", head[9], head[10], head[11], head[8], head[12], head[3]);
   }
+  if (misses) {
+    *misses = head[13];
+    if (head[13]) return ISL_OK;  // a round of the recompute provider: statuses are not final yet
+  }
   for (uint64_t i = 0; i < nq; i++) {  // first failing query wins, like the sequential map
     if (status[i] == QS_OK) continue;
     if (status[i] == QS_NODE_NOT_FOUND) {
@@ -1319,6 +1363,90 @@ isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws) {
     return isl::fail(ISL_ERR_SEARCH, "Search error: query %llu left in state 0x%x",
                      (unsigned long long)i, status[i]);
   }
+  return ISL_OK;
+}
+
+// ---- recompute provider (EmbeddingProvider backed by the encoder, leann.rs:82-99) ----
+// marks the missed ids present and lists each of them once
+__global__ void dedupe_misses_kernel(const uint32_t* __restrict__ miss, uint32_t n,
+                                     uint32_t* __restrict__ present, uint32_t* __restrict__ uniq,
+                                     uint32_t* __restrict__ uniq_count) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t id = miss[i], bit = 1u << (id & 31);
+  const uint32_t old = atomicOr(&present[id >> 5], bit);
+  if (!(old & bit)) uniq[atomicAdd(uniq_count, 1u)] = id;
+}
+
+// norm2[id] = sum_j row[id][j]^2 in the reference's order for the freshly encoded rows
+__global__ __launch_bounds__(64) void row_norm2_list_kernel(const float* __restrict__ emb, uint64_t stride,
+                                                            uint32_t d, const uint32_t* __restrict__ ids,
+                                                            uint32_t n, float* __restrict__ norm2) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* tile = reinterpret_cast<float*>(smem);
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {
+    const uint32_t R = n - base < 64 ? n - base : 64;
+    const uint32_t uid = lane < R ? ids[base + lane] : 0u;
+    const float v = wave_distances<METRIC_SUMSQ_RAW>(emb, stride, d, uid, R, tile, tile, 0.f);
+    if (lane < R) norm2[uid] = v;
+  }
+}
+
+// One synchronous search.  With the in-memory provider: enqueue + finish.  With the recompute
+// provider: rounds of (search; every query that needs an absent row reports it and stops) ->
+// (encode the reported nodes once each) until a round completes without a miss; that last round
+// is an ordinary search over materialised rows, so ids, distances, counters and error behaviour
+// are those of the in-memory provider holding the same embeddings.  Re-running the batch per
+// round costs traversal time only, which is noise next to the encoder (5.5 GFLOP per node).
+isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const float* d_queries,
+                       uint64_t nq, uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_ids,
+                       float* d_dist, uint32_t* d_count, hipStream_t user_stream, StreamMode mode) {
+  if (!idx->recompute) {
+    ISL_TRY(search_enqueue(idx, ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, user_stream, mode));
+    return search_finish(idx, ws);
+  }
+  const uint64_t cap = std::min<uint64_t>(nq * 64 + 64, 0xFFFFFFF0ull);
+  if (ws.miss_cap < cap) {
+    void* ptrs[] = {ws.miss, ws.uniq, ws.uniq_count};
+    for (void* q : ptrs)
+      if (q) (void)hipFree(q);
+    ws.miss = ws.uniq = ws.uniq_count = nullptr;
+    ws.miss_cap = 0;
+    ISL_HIP(hipMalloc(&ws.miss, cap * 4));
+    ISL_HIP(hipMalloc(&ws.uniq, cap * 4));
+    ISL_HIP(hipMalloc(&ws.uniq_count, 4));
+    ws.miss_cap = cap;
+  }
+  hipStream_t st = mode == StreamMode::USER ? user_stream : ws.stream;
+  if (!idx->keep_rows) ISL_HIP(hipMemsetAsync(idx->d_present, 0, idx->present_words * 4, st));
+  uint64_t encoded = 0, rounds = 0;
+  double kernel_ms = 0.0;
+  for (;;) {
+    ISL_TRY(search_enqueue(idx, ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, user_stream, mode));
+    uint32_t misses = 0;
+    ISL_TRY(search_finish(idx, ws, &misses));
+    kernel_ms += idx->stats.kernel_ms;
+    rounds += 1;
+    if (!misses) break;
+    if (misses > ws.miss_cap) misses = (uint32_t)ws.miss_cap;
+    ISL_HIP(hipMemsetAsync(ws.uniq_count, 0, 4, st));
+    hipLaunchKernelGGL(dedupe_misses_kernel, dim3((misses + 255) / 256), dim3(256), 0, st, ws.miss, misses,
+                       idx->d_present, ws.uniq, ws.uniq_count);
+    uint32_t nu = 0;
+    ISL_HIP(hipMemcpyAsync(&nu, ws.uniq_count, 4, hipMemcpyDeviceToHost, st));
+    ISL_HIP(hipStreamSynchronize(st));
+    ISL_TRY(isl::encoder_embed_nodes(idx->enc, idx->d_tokens, idx->d_lens, idx->tok_L, ws.uniq, nu,
+                                     idx->enc_normalize, idx->d_emb, idx->emb_stride, st));
+    const size_t lds = (size_t)TILE_ROWS * TILE_LD * 4 + 64;
+    hipLaunchKernelGGL(row_norm2_list_kernel, dim3(std::min<uint32_t>((nu + 63) / 64, 4096)), dim3(64), lds, st,
+                       idx->d_emb, idx->emb_stride, (uint32_t)idx->emb_d, ws.uniq, nu, idx->d_norm2);
+    ISL_HIP(hipGetLastError());
+    encoded += nu;
+  }
+  idx->stats.encoded_nodes = encoded;
+  idx->stats.recompute_rounds = rounds;
+  idx->stats.kernel_ms = kernel_ms;
   return ISL_OK;
 }
 
@@ -1380,9 +1508,8 @@ isl_status isl_search_batch_device(const isl_index* idx, const float* d_queries,
   std::lock_guard<std::mutex> lock(idx->mu);
   isl::SearchWorkspace* ws = free_lane(idx);
   if (!ws) return isl::fail(ISL_ERR_SEARCH, "Search error: every search lane has a call in flight");
-  ISL_TRY(search_enqueue(idx, *ws, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count,
-                         (hipStream_t)stream, StreamMode::USER));
-  return search_finish(idx, *ws);
+  return search_sync(idx, *ws, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count,
+                     (hipStream_t)stream, StreamMode::USER);
 }
 
 isl_status isl_search_batch_device_async(const isl_index* idx, const float* d_queries, uint64_t nq,
@@ -1397,6 +1524,8 @@ isl_status isl_search_batch_device_async(const isl_index* idx, const float* d_qu
   if (!d_queries || !d_out_count || (k && (!d_out_ids || !d_out_dist)))
     return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
   ISL_TRY(isl::use_device(idx->device));
+  if (idx->recompute)
+    return isl::fail(ISL_ERR_UNSUPPORTED, "the recompute provider answers synchronously: use isl_search_batch_device");
   std::lock_guard<std::mutex> lock(idx->mu);
   isl::SearchWorkspace* ws = free_lane(idx);
   if (!ws)
@@ -1454,9 +1583,8 @@ isl_status isl_search_batch(const isl_index* idx, const float* queries, uint64_t
     ws.out_stage_slots = slots;
   }
   ISL_HIP(hipMemcpy(ws.q_stage, queries, qbytes, hipMemcpyHostToDevice));
-  ISL_TRY(search_enqueue(idx, ws, ws.q_stage, nq, d, k, ef, ws.ids_stage, ws.dist_stage,
-                         ws.count_stage, nullptr, StreamMode::OWN));
-  ISL_TRY(search_finish(idx, ws));
+  ISL_TRY(search_sync(idx, ws, ws.q_stage, nq, d, k, ef, ws.ids_stage, ws.dist_stage, ws.count_stage,
+                      nullptr, StreamMode::OWN));
   if (k) {
     ISL_HIP(hipMemcpy(out_ids, ws.ids_stage, nq * k * 8, hipMemcpyDeviceToHost));
     ISL_HIP(hipMemcpy(out_dist, ws.dist_stage, nq * k * 4, hipMemcpyDeviceToHost));

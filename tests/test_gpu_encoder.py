@@ -90,3 +90,80 @@ def test_encoder_errors():
         ia.CandleEmbedder(ia.BertConfig(hidden=30, heads=4))
     assert e.value.kind == "InvalidConfig"
     assert enc.embed(np.zeros((0, 4), np.int64)).shape == (0, 32)
+
+
+# ------------------------------------------------- recompute provider (leann.rs:82-99)
+def _recompute_case(orc, n=1200, L=12, seed=5):
+    cfg = dict(vocab_size=400, hidden=64, layers=2, heads=4, intermediate=128, max_position=16, type_vocab=2)
+    w = bert_ref.random_weights(cfg, seed=45, std=0.2)
+    enc = ia.CandleEmbedder(to_cfg(cfg), w, normalize=True)
+    rng = np.random.default_rng(seed)
+    # "documents" = a topic prefix plus noise tokens, so that embeddings cluster
+    topics = rng.integers(1, 400, (24, 6))
+    tok = np.zeros((n, L), np.uint16)
+    lens = rng.integers(3, L + 1, n).astype(np.uint16)
+    for i in range(n):
+        row = np.concatenate([topics[rng.integers(0, 24)], rng.integers(1, 400, L - 6)])
+        tok[i] = row
+        tok[i, lens[i]:] = 0
+    ids = tok.astype(np.int64)
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.float32)
+    emb = np.concatenate([enc.embed(ids[o:o + 256], None, mask[o:o + 256]) for o in range(0, n, 256)])
+    return cfg, enc, tok, lens, emb
+
+
+def test_recompute_provider_equals_in_memory_provider(orc):
+    """The search over embeddings recomputed on the fly must return what the search over the
+    same embeddings held in memory returns (which the parity tests pin to the oracle)."""
+    cfg, enc, tok, lens, emb = _recompute_case(orc)
+    n = emb.shape[0]
+    levels = np.zeros(n, np.uint64)
+    levels[0] = 2
+    csr = orc.leann_build(emb, m=8, m0=16, ef_construction=40, levels=levels)
+    g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels,
+                    entry_point=csr.entry_point, max_level=csr.max_level, num_nodes=csr.num_nodes,
+                    degree_counts=csr.degree_counts)
+    q = emb[::97] + np.float32(0.01)
+    mem_idx = ia.LeannIndex.from_csr(g, None, dimension=64)
+    mem_idx.upload(0)
+    mem_idx.set_embeddings(emb)
+    want = mem_idx.search_batch(q, 10, 48)
+    want_stats = mem_idx.last_stats()
+    rec_idx = ia.LeannIndex.from_csr(g, None, dimension=64)
+    rec_idx.upload(0)
+    rec_idx.set_recompute_provider(enc, tok, lens)
+    assert rec_idx.is_recompute()
+    for rep in range(2):  # keep_rows = False: the second call recomputes everything again
+        got = rec_idx.search_batch(q, 10, 48)
+        st = rec_idx.last_stats()
+        assert got[2].tolist() == want[2].tolist()
+        assert got[0].tolist() == want[0].tolist()
+        assert got[1].view(np.uint32).tolist() == want[1].view(np.uint32).tolist()
+        for f in ("expansions", "edges", "evals", "pushes"):
+            assert st[f] == want_stats[f], f
+        assert st["recompute_rounds"] > 2
+        # every node is encoded once per call, however many queries visit it
+        assert 0 < st["encoded_nodes"] <= min(want_stats["evals"], n)
+    # and against the oracle directly
+    for i in range(q.shape[0]):
+        r = orc.leann_search(csr, emb, q[i], 10, 48)
+        c = int(got[2][i])
+        assert got[0][i, :c].tolist() == r.ids.tolist()
+
+
+def test_recompute_provider_keeps_rows_when_asked(orc):
+    cfg, enc, tok, lens, emb = _recompute_case(orc, n=400, seed=9)
+    levels = np.zeros(400, np.uint64)
+    csr = orc.leann_build(emb, m=6, m0=12, ef_construction=30, levels=levels)
+    g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels,
+                    entry_point=csr.entry_point, max_level=csr.max_level, num_nodes=csr.num_nodes,
+                    degree_counts=csr.degree_counts)
+    idx = ia.LeannIndex.from_csr(g, None, dimension=64)
+    idx.upload(0)
+    idx.set_recompute_provider(enc, tok, lens, keep_rows=True)
+    a = idx.search_batch(emb[:8], 5, 20)
+    first = idx.last_stats()
+    b = idx.search_batch(emb[:8], 5, 20)
+    second = idx.last_stats()
+    assert a[0].tolist() == b[0].tolist() and first["encoded_nodes"] > 0
+    assert second["encoded_nodes"] == 0 and second["recompute_rounds"] == 1
