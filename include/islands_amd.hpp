@@ -165,6 +165,13 @@ class LeannIndex {
   void attach(const InMemoryEmbeddingProvider& p) {
     check(isl_set_embeddings(h_, p.embeddings.data(), p.len(), p.dim, ISL_DTYPE_F32, ISL_MEM_HOST));
   }
+  // recompute mode: EmbeddingProvider backed by the encoder (leann.rs:82-99); the embedder is
+  // borrowed and must outlive the index
+  void attach_recompute(isl_encoder* enc, const std::vector<uint16_t>& tokens, uint64_t n, uint64_t L,
+                        bool normalize = true, bool keep_rows = false) {
+    check(isl_set_recompute_provider(h_, enc, tokens.data(), nullptr, n, L, normalize ? 1 : 0,
+                                     keep_rows ? 1 : 0, ISL_MEM_HOST));
+  }
   // search / search_with_params, leann.rs:858-896
   std::vector<std::pair<uint64_t, float>> search(const std::vector<float>& query, uint64_t k) const {
     return search_with_params(query, k, config().ef_search);
@@ -184,6 +191,143 @@ class LeannIndex {
  private:
   explicit LeannIndex(std::nullptr_t) {}
   isl_index* h_ = nullptr;
+};
+
+// ---- hnsw.rs / search.rs facade ------------------------------------------------------------
+// SearchResult, src/core/search.rs:54-103
+struct SearchResult {
+  uint64_t id = 0;
+  float score = 0.f;
+  std::optional<std::vector<float>> vector;
+  std::optional<std::string> text;
+  float to_similarity() const { return 1.0f / (1.0f + score); }  // search.rs:100-102
+};
+
+// SearchConfig, src/core/search.rs:8-52
+struct SearchConfig {
+  uint64_t top_k = 10, ef = 100;
+  bool include_vectors = false, include_metadata = true;
+  std::optional<float> min_similarity;
+  static SearchConfig fast(uint64_t k) { SearchConfig c; c.top_k = k; c.ef = k * 2; return c; }
+  static SearchConfig accurate(uint64_t k) { SearchConfig c; c.top_k = k; c.ef = k * 10; return c; }
+};
+
+// Search side of HnswGraph, src/core/hnsw.rs:149-515.  Insertion (hnsw.rs:214-329) is outside
+// the search path: the graph is handed over layer by layer (layers[L][node] = neighbour ids).
+class HnswGraph {
+ public:
+  HnswGraph(const std::vector<float>& vectors, uint64_t dim,
+            const std::vector<std::vector<std::vector<uint64_t>>>& layers,
+            const std::vector<uint64_t>& levels, std::optional<uint64_t> entry_point, uint64_t max_level,
+            uint64_t m = 16, uint64_t m0 = 32, uint64_t ef_construction = 200,
+            DistanceMetric metric = DistanceMetric::Cosine, int32_t device = 0)
+      : vectors_(vectors), dim_(dim) {
+    const uint64_t n = levels.size();
+    std::vector<std::vector<uint64_t>> offs(layers.size()), adjs(layers.size());
+    std::vector<const uint64_t*> po, pa;
+    for (size_t L = 0; L < layers.size(); L++) {
+      offs[L].assign(1, 0);
+      for (uint64_t i = 0; i < n; i++) {
+        adjs[L].insert(adjs[L].end(), layers[L][i].begin(), layers[L][i].end());
+        offs[L].push_back(adjs[L].size());
+      }
+      if (adjs[L].empty()) adjs[L].push_back(0);
+      po.push_back(offs[L].data());
+      pa.push_back(adjs[L].data());
+    }
+    check(isl_hnsw_from_layers(m, m0, ef_construction, (int32_t)metric, n, dim, layers.size(), po.data(),
+                               pa.data(), n ? levels.data() : nullptr, entry_point ? 1 : 0,
+                               entry_point.value_or(0), max_level, n ? vectors.data() : nullptr, device, &h_));
+  }
+  HnswGraph(const HnswGraph&) = delete;
+  HnswGraph& operator=(const HnswGraph&) = delete;
+  ~HnswGraph() { isl_hnsw_free(h_); }
+  uint64_t len() const { return isl_hnsw_len(h_); }
+  bool is_empty() const { return len() == 0; }
+  // HnswGraph::search, hnsw.rs:458-504
+  std::vector<std::pair<uint64_t, float>> search(const std::vector<float>& query, uint64_t k, uint64_t ef) const {
+    return search_batch(query, 1, k, ef)[0];
+  }
+  std::vector<std::vector<std::pair<uint64_t, float>>> search_batch(const std::vector<float>& queries,
+                                                                    uint64_t nq, uint64_t k, uint64_t ef) const {
+    std::vector<uint64_t> ids(nq * (k ? k : 1));
+    std::vector<float> dist(nq * (k ? k : 1));
+    std::vector<uint32_t> cnt(nq);
+    check(isl_hnsw_search_batch(h_, queries.data(), nq, nq ? queries.size() / nq : 0, k, ef, ids.data(),
+                                dist.data(), cnt.data()));
+    std::vector<std::vector<std::pair<uint64_t, float>>> out(nq);
+    for (uint64_t q = 0; q < nq; q++)
+      for (uint32_t i = 0; i < cnt[q]; i++) out[q].emplace_back(ids[q * k + i], dist[q * k + i]);
+    return out;
+  }
+  std::optional<std::vector<float>> get_vector(uint64_t id) const {  // get_node(id).vector, hnsw.rs:507-510
+    if (id >= len()) return std::nullopt;
+    return std::vector<float>(vectors_.begin() + id * dim_, vectors_.begin() + (id + 1) * dim_);
+  }
+
+ private:
+  isl_hnsw* h_ = nullptr;
+  std::vector<float> vectors_;
+  uint64_t dim_ = 0;
+};
+
+// Searcher, src/core/search.rs:105-182; search_batch is one device launch instead of the
+// reference's sequential map (:179-181).
+class Searcher {
+ public:
+  explicit Searcher(const HnswGraph& g, SearchConfig c = SearchConfig()) : graph_(g), config_(c) {}
+  Searcher& top_k(uint64_t k) { config_.top_k = k; return *this; }
+  Searcher& ef(uint64_t e) { config_.ef = e; return *this; }
+  Searcher& include_vectors() { config_.include_vectors = true; return *this; }
+  Searcher& min_similarity(float t) { config_.min_similarity = t; return *this; }
+  std::vector<SearchResult> search(const std::vector<float>& query) const { return search_batch(query, 1)[0]; }
+  std::vector<std::vector<SearchResult>> search_batch(const std::vector<float>& queries, uint64_t nq) const {
+    auto raw = graph_.search_batch(queries, nq, config_.top_k, config_.ef);
+    std::vector<std::vector<SearchResult>> out(nq);
+    for (uint64_t q = 0; q < nq; q++)
+      for (auto& [id, d] : raw[q]) {
+        SearchResult r;
+        r.id = id;
+        r.score = d;
+        if (config_.include_vectors) r.vector = graph_.get_vector(id);
+        if (!config_.min_similarity || r.to_similarity() >= *config_.min_similarity) out[q].push_back(std::move(r));
+      }
+    return out;
+  }
+
+ private:
+  const HnswGraph& graph_;
+  SearchConfig config_;
+};
+
+// ---- embedding/candle_provider.rs ---------------------------------------------------------
+// CandleEmbedder after tokenisation (candle_provider.rs:226-507): weights by checkpoint tensor
+// name, embed = embed_texts_raw on padded token ids.
+class CandleEmbedder {
+ public:
+  CandleEmbedder(const isl_bert_config& cfg, bool normalize = true, int32_t device = 0)
+      : cfg_(cfg), normalize_(normalize) { check(isl_encoder_new(&cfg, device, &h_)); }
+  CandleEmbedder(const CandleEmbedder&) = delete;
+  CandleEmbedder& operator=(const CandleEmbedder&) = delete;
+  ~CandleEmbedder() { isl_encoder_free(h_); }
+  void set_weight(const std::string& name, const std::vector<float>& v) {
+    check(isl_encoder_set_weight(h_, name.c_str(), v.data(), v.size(), ISL_MEM_HOST));
+  }
+  uint64_t dimension() const { return cfg_.hidden; }
+  // ids / mask: B rows of L entries (padding: id 0, mask 0, candle_provider.rs:385-402)
+  std::vector<float> embed(const std::vector<int64_t>& ids, const std::vector<float>& mask, uint64_t B,
+                           uint64_t L) const {
+    std::vector<float> out(B * cfg_.hidden);
+    check(isl_encoder_embed(h_, ids.data(), nullptr, mask.empty() ? nullptr : mask.data(), B, L,
+                            normalize_ ? 1 : 0, out.data(), ISL_MEM_HOST, nullptr));
+    return out;
+  }
+  isl_encoder* handle() const { return h_; }
+
+ private:
+  isl_encoder* h_ = nullptr;
+  isl_bert_config cfg_;
+  bool normalize_;
 };
 
 }  // namespace islands::core

@@ -96,6 +96,41 @@ static void test_gpu() {
   EXPECT(throws(ISL_ERR_DIMENSION_MISMATCH, [&] { idx.search(std::vector<float>(8, 0.5f), 5); }));  // :1315-1325
   LeannIndex empty = LeannIndex::with_defaults();  // :1306-1313
   EXPECT(empty.search(std::vector<float>(8, 0.5f), 5).empty());
+
+  // HnswGraph facade + Searcher (hnsw.rs:458-504, search.rs:324-400) on a two-layer graph: layer 1
+  // links every 10th node into a ring, layer 0 is the chord ring from above
+  std::vector<std::vector<std::vector<uint64_t>>> layers(2, std::vector<std::vector<uint64_t>>(n));
+  std::vector<uint64_t> levels(n, 0);
+  for (size_t i = 0; i < n; i++) {
+    layers[0][i] = {(i + 1) % n, (i + n - 1) % n, (i + 7) % n};
+    if (i % 10 == 0) { levels[i] = 1; layers[1][i] = {(i + 10) % n, (i + n - 10) % n}; }
+  }
+  HnswGraph hg(vecs, d, layers, levels, 0, 1);
+  EXPECT(hg.len() == n && !hg.is_empty());
+  auto hres = hg.search(q, 5, 200);
+  EXPECT(hres.size() == 5 && hres[0].first == 0 && hres[0].second < 0.01f);
+  Searcher s(hg);
+  EXPECT(s.top_k(5).search(q).size() == 5);
+  for (auto& r : Searcher(hg).include_vectors().top_k(3).search(q)) EXPECT(r.vector && r.vector->size() == d);
+  for (auto& r : Searcher(hg).min_similarity(0.5f).search(q)) EXPECT(r.to_similarity() >= 0.5f);
+  EXPECT(SearchConfig::fast(5).ef == 10 && SearchConfig::accurate(5).ef == 50);  // search.rs:285-297
+  SearchResult sr;
+  sr.score = 1.0f;
+  EXPECT(sr.to_similarity() == 0.5f);  // search.rs:311-324
+
+  // CandleEmbedder (candle_provider.rs:353-507) with all-zero weights except LayerNorm scale 1:
+  // every hidden state is LayerNorm(0) = bias = 0 -> pooled 0 -> the 1e-12 norm floor keeps it 0
+  isl_bert_config bc{50, 32, 1, 2, 64, 16, 1, 1e-12f, 0};
+  CandleEmbedder enc(bc);
+  std::vector<int64_t> ids = {1, 2, 3, 0, 4, 5, 0, 0};
+  std::vector<float> mask = {1, 1, 1, 0, 1, 1, 0, 0};
+  auto emb = enc.embed(ids, mask, 2, 4);
+  EXPECT(emb.size() == 64);
+  bool all_zero = true;
+  for (float v : emb) all_zero = all_zero && v == 0.0f;
+  EXPECT(all_zero);
+  EXPECT(throws(ISL_ERR_DIMENSION_MISMATCH, [&] { enc.set_weight("embeddings.LayerNorm.bias", std::vector<float>(5)); }));
+  EXPECT(throws(ISL_ERR_EMBEDDING, [&] { enc.embed({99, 1, 1, 1}, {1, 1, 1, 1}, 1, 4); }));
 }
 
 int main(int argc, char** argv) {
