@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--per-cluster", type=int, default=1000)
     ap.add_argument("--mode", choices=["shard", "replica"], default="shard")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-replica", action="store_true",
+                    help="multi-GPU shard runs: skip the extra replica-mode measurement")
     ap.add_argument("--distinct-batches", type=int, default=4)
     ap.add_argument("--pipeline", type=int, default=8,
                     help="searches kept in flight (isl_search_batch_device_async); 1 = synchronous")
@@ -153,204 +155,223 @@ def main():
     from islands_amd import synth
 
     N, d, nq, k, ef = args.nodes, args.dim, args.nq, args.k, args.ef
-    shard_mode = world > 1 and args.mode == "shard"
-    if shard_mode:
-        lo = rank * N // world
-        hi = (rank + 1) * N // world
-    else:
-        lo, hi = 0, N
-    n_local = hi - lo
-
-    # ---------------- setup (untimed): data, graph, index upload, queries, ground truth
-    t0 = time.time()
-    x = synth.make_rows(N, d, lo, n_local, per_cluster=args.per_cluster, device=dev)
-    torch.cuda.synchronize()
-    log(f"rows [{lo},{hi}) generated in {time.time() - t0:.1f}s")
-    t0 = time.time()
-    offsets, neighbours, entry = synth.build_graph(x, m0=60)
-    torch.cuda.synchronize()
-    gst = synth.graph_stats(offsets)
-    log(f"graph built in {time.time() - t0:.1f}s: {gst}")
-    t0 = time.time()
-    cfg = ia.LeannConfig.paper_default()
-    idx = ia.LeannIndex.from_device_csr(offsets.data_ptr(), neighbours.data_ptr(), n_local, entry,
-                                        d, cfg, device=local_rank)
-    idx.set_embeddings(None, device_ptr=x.data_ptr(), n=n_local, d=d)
-    log(f"index resident in {time.time() - t0:.1f}s")
-
-    nb_batches = max(1, min(args.distinct_batches, args.steps + args.warmup))
-    qsets, truths = [], []
-    for b in range(nb_batches):
-        # replica mode: every rank answers its own batches; shard mode: same batch on all ranks
-        qoff = (b + (rank * nb_batches if (world > 1 and not shard_mode) else 0)) * nq
-        q = synth.make_rows(N, d, qoff, nq, per_cluster=args.per_cluster, device=dev, query=True)
-        qsets.append(q.contiguous())
-        ti, td = synth.brute_force_topk(x, q, k)
-        truths.append((ti + lo, td))
-    torch.cuda.synchronize()
-
-    depth = max(1, min(args.pipeline, 16))
-    # one output set per search in flight
-    outs = [(torch.zeros((nq, k), dtype=torch.int64, device=dev),
-             torch.zeros((nq, k), dtype=torch.float32, device=dev),
-             torch.zeros(nq, dtype=torch.int32, device=dev)) for _ in range(depth)]
-    if shard_mode:
-        g_ids = torch.zeros((world, nq, k), dtype=torch.int64, device=dev)
-        g_dist = torch.zeros((world, nq, k), dtype=torch.float32, device=dev)
-        g_cnt = torch.zeros((world, nq), dtype=torch.int32, device=dev)
-        m_ids = torch.zeros((nq, k), dtype=torch.int64, device=dev)
-        m_dist = torch.zeros((nq, k), dtype=torch.float32, device=dev)
-        m_src = torch.zeros((nq, k), dtype=torch.int32, device=dev)
-        m_cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
-        id_base = np.array([r * N // world for r in range(world)], dtype=np.uint64)
-        # exact global truth = merge of the per-shard exact top-k (same collective + merge)
-        g_truth = []
-        for (ti, td) in truths:
-            gi_all = torch.zeros((world * nq, k), dtype=ti.dtype, device=dev)
-            gd_all = torch.zeros((world * nq, k), dtype=td.dtype, device=dev)
-            all_gather_rows(gi_all, ti.contiguous())
-            all_gather_rows(gd_all, td.contiguous())
-            ci = gi_all.view(world, nq, k).permute(1, 0, 2).reshape(nq, world * k)
-            cd = gd_all.view(world, nq, k).permute(1, 0, 2).reshape(nq, world * k)
-            sel = torch.topk(cd, k, dim=1, largest=False).indices
-            g_truth.append(torch.gather(ci, 1, sel))
-
-    import ctypes as C
-    from islands_amd import _ffi
-
-    def enqueue(b):
-        """One step = one pass of the hot path over one resident query batch."""
-        q = qsets[b % nb_batches]
-        o = outs[b % depth]
-        return idx.search_batch_device_async(q.data_ptr(), nq, d, k, ef, o[0].data_ptr(),
-                                             o[1].data_ptr(), o[2].data_ptr())
-
-    def finish(b, token):
-        idx.wait(token)
-        st = idx.last_stats()
-        o = outs[b % depth]
+    def measure(mode):
+        """One full measurement (setup, warm-up, timed steps) in `mode`; returns the result
+        object and what the CPU baseline needs."""
+        shard_mode = world > 1 and mode == "shard"
         if shard_mode:
-            # the one exchange step of the path: per-shard top-k over xGMI (RCCL all-gather)
-            all_gather_rows(g_ids.view(world * nq, k), o[0])
-            all_gather_rows(g_dist.view(world * nq, k), o[1])
-            all_gather_rows(g_cnt.view(world * nq), o[2])
-            torch.cuda.synchronize()
-            ia._check(_ffi.lib().isl_merge_topk(
-                world, nq, k, C.c_void_p(g_ids.data_ptr()), C.c_void_p(g_dist.data_ptr()),
-                C.c_void_p(g_cnt.data_ptr()), id_base.ctypes.data_as(C.c_void_p), k,
-                C.c_void_p(m_ids.data_ptr()), C.c_void_p(m_dist.data_ptr()),
-                C.c_void_p(m_src.data_ptr()), C.c_void_p(m_cnt.data_ptr()), 1, local_rank, None))
-            return st, (m_ids, m_cnt)
-        return st, (o[0], o[2])
+            lo = rank * N // world
+            hi = (rank + 1) * N // world
+        else:
+            lo, hi = 0, N
+        n_local = hi - lo
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+        # ---------------- setup (untimed): data, graph, index upload, queries, ground truth
+        t0 = time.time()
+        x = synth.make_rows(N, d, lo, n_local, per_cluster=args.per_cluster, device=dev)
+        torch.cuda.synchronize()
+        log(f"rows [{lo},{hi}) generated in {time.time() - t0:.1f}s")
+        t0 = time.time()
+        offsets, neighbours, entry = synth.build_graph(x, m0=60)
+        torch.cuda.synchronize()
+        gst = synth.graph_stats(offsets)
+        log(f"graph built in {time.time() - t0:.1f}s: {gst}")
+        t0 = time.time()
+        cfg = ia.LeannConfig.paper_default()
+        idx = ia.LeannIndex.from_device_csr(offsets.data_ptr(), neighbours.data_ptr(), n_local, entry,
+                                            d, cfg, device=local_rank)
+        idx.set_embeddings(None, device_ptr=x.data_ptr(), n=n_local, d=d)
+        log(f"index resident in {time.time() - t0:.1f}s")
+
+        nb_batches = max(1, min(args.distinct_batches, args.steps + args.warmup))
+        qsets, truths = [], []
+        for b in range(nb_batches):
+            # replica mode: every rank answers its own batches; shard mode: same batch on all ranks
+            qoff = (b + (rank * nb_batches if (world > 1 and not shard_mode) else 0)) * nq
+            q = synth.make_rows(N, d, qoff, nq, per_cluster=args.per_cluster, device=dev, query=True)
+            qsets.append(q.contiguous())
+            ti, td = synth.brute_force_topk(x, q, k)
+            truths.append((ti + lo, td))
         torch.cuda.synchronize()
 
-    def run(first, count, collect):
-        """Runs steps [first, first+count) with `depth` searches in flight."""
-        agg = {"queries": 0, "expansions": 0, "edges": 0, "evals": 0, "pushes": 0,
-               "exact_path": 0, "replayed": 0, "kernel_ms": 0.0}
-        kept = []
-        pending = []
-        for s in range(first, first + count):
-            pending.append((s, enqueue(s)))
-            if len(pending) >= depth:
+        depth = max(1, min(args.pipeline, 16))
+        # one output set per search in flight
+        outs = [(torch.zeros((nq, k), dtype=torch.int64, device=dev),
+                 torch.zeros((nq, k), dtype=torch.float32, device=dev),
+                 torch.zeros(nq, dtype=torch.int32, device=dev)) for _ in range(depth)]
+        if shard_mode:
+            g_ids = torch.zeros((world, nq, k), dtype=torch.int64, device=dev)
+            g_dist = torch.zeros((world, nq, k), dtype=torch.float32, device=dev)
+            g_cnt = torch.zeros((world, nq), dtype=torch.int32, device=dev)
+            m_ids = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+            m_dist = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+            m_src = torch.zeros((nq, k), dtype=torch.int32, device=dev)
+            m_cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+            id_base = np.array([r * N // world for r in range(world)], dtype=np.uint64)
+            # exact global truth = merge of the per-shard exact top-k (same collective + merge)
+            g_truth = []
+            for (ti, td) in truths:
+                gi_all = torch.zeros((world * nq, k), dtype=ti.dtype, device=dev)
+                gd_all = torch.zeros((world * nq, k), dtype=td.dtype, device=dev)
+                all_gather_rows(gi_all, ti.contiguous())
+                all_gather_rows(gd_all, td.contiguous())
+                ci = gi_all.view(world, nq, k).permute(1, 0, 2).reshape(nq, world * k)
+                cd = gd_all.view(world, nq, k).permute(1, 0, 2).reshape(nq, world * k)
+                sel = torch.topk(cd, k, dim=1, largest=False).indices
+                g_truth.append(torch.gather(ci, 1, sel))
+
+        import ctypes as C
+        from islands_amd import _ffi
+
+        def enqueue(b):
+            """One step = one pass of the hot path over one resident query batch."""
+            q = qsets[b % nb_batches]
+            o = outs[b % depth]
+            return idx.search_batch_device_async(q.data_ptr(), nq, d, k, ef, o[0].data_ptr(),
+                                                 o[1].data_ptr(), o[2].data_ptr())
+
+        def finish(b, token):
+            idx.wait(token)
+            st = idx.last_stats()
+            o = outs[b % depth]
+            if shard_mode:
+                # the one exchange step of the path: per-shard top-k over xGMI (RCCL all-gather)
+                all_gather_rows(g_ids.view(world * nq, k), o[0])
+                all_gather_rows(g_dist.view(world * nq, k), o[1])
+                all_gather_rows(g_cnt.view(world * nq), o[2])
+                # no device-wide synchronize here: it would wait for the other searches in flight.
+                # The collectives are ordered on torch's current (= the default) stream, which is
+                # the stream the merge below is launched on.
+                ia._check(_ffi.lib().isl_merge_topk(
+                    world, nq, k, C.c_void_p(g_ids.data_ptr()), C.c_void_p(g_dist.data_ptr()),
+                    C.c_void_p(g_cnt.data_ptr()), id_base.ctypes.data_as(C.c_void_p), k,
+                    C.c_void_p(m_ids.data_ptr()), C.c_void_p(m_dist.data_ptr()),
+                    C.c_void_p(m_src.data_ptr()), C.c_void_p(m_cnt.data_ptr()), 1, local_rank, None))
+                return st, (m_ids, m_cnt)
+            return st, (o[0], o[2])
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        def run(first, count, collect):
+            """Runs steps [first, first+count) with `depth` searches in flight."""
+            agg = {"queries": 0, "expansions": 0, "edges": 0, "evals": 0, "pushes": 0,
+                   "exact_path": 0, "replayed": 0, "kernel_ms": 0.0}
+            kept = []
+            pending = []
+            for s in range(first, first + count):
+                pending.append((s, enqueue(s)))
+                if len(pending) >= depth:
+                    b, tok = pending.pop(0)
+                    st, res = finish(b, tok)
+                    for f in agg:
+                        agg[f] += st[f]
+                    if collect and len(kept) < nb_batches:
+                        kept.append((b % nb_batches, res[0].clone(), res[1].clone()))
+            while pending:
                 b, tok = pending.pop(0)
                 st, res = finish(b, tok)
                 for f in agg:
                     agg[f] += st[f]
                 if collect and len(kept) < nb_batches:
                     kept.append((b % nb_batches, res[0].clone(), res[1].clone()))
-        while pending:
-            b, tok = pending.pop(0)
-            st, res = finish(b, tok)
-            for f in agg:
-                agg[f] += st[f]
-            if collect and len(kept) < nb_batches:
-                kept.append((b % nb_batches, res[0].clone(), res[1].clone()))
-        return agg, kept
+            return agg, kept
 
-    run(0, args.warmup, False)
-    barrier()
-    t0 = time.perf_counter()
-    agg, recalls = run(args.warmup, args.steps, True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        run(0, args.warmup, False)
+        barrier()
+        t0 = time.perf_counter()
+        agg, recalls = run(args.warmup, args.steps, True)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
 
-    rec = []
-    for (b, ids_b, cnt_b) in recalls:
-        truth = g_truth[b] if shard_mode else truths[b][0]
-        rec.append(synth.recall_at_k(ids_b, cnt_b, truth))
-    recall = float(np.mean(rec)) if rec else 0.0
+        rec = []
+        for (b, ids_b, cnt_b) in recalls:
+            truth = g_truth[b] if shard_mode else truths[b][0]
+            rec.append(synth.recall_at_k(ids_b, cnt_b, truth))
+        recall = float(np.mean(rec)) if rec else 0.0
 
-    queries_per_step = nq if (world == 1 or shard_mode) else nq * world
-    value = queries_per_step * args.steps / elapsed
-    kernel_ms = agg["kernel_ms"] / max(args.steps, 1)
-    bytes_per_launch = algorithmic_bytes(agg, d, k) / max(args.steps, 1)
-    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    agg_gbs = algorithmic_bytes(agg, d, k) / elapsed / 1e9
-    # HBM bytes per launch come from a separate rocprofv3 --pmc FETCH_SIZE pass (counters cannot be
-    # read from inside this process); the committed measurement applies to the headline workload only
-    traffic_env = os.environ.get("ISL_TRAFFIC_BYTES")
-    traffic_src = None
-    if not traffic_env and world == 1 and (N, d, nq, ef, k) == (10_000_000, 768, 1024, 128, 10):
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch.json")) as fh:
-                traffic_env = str(json.load(fh)["search"]["hbm_bytes_per_launch"])
-                traffic_src = "profiles/r01_pmc_fetch.json (rocprofv3 --pmc FETCH_SIZE x 1024 x 2)"
-        except (OSError, KeyError, ValueError):
-            traffic_env = None
+        queries_per_step = nq if (world == 1 or shard_mode) else nq * world
+        value = queries_per_step * args.steps / elapsed
+        kernel_ms = agg["kernel_ms"] / max(args.steps, 1)
+        bytes_per_launch = algorithmic_bytes(agg, d, k) / max(args.steps, 1)
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        agg_gbs = algorithmic_bytes(agg, d, k) / elapsed / 1e9
+        # HBM bytes per launch come from a separate rocprofv3 --pmc FETCH_SIZE pass (counters cannot be
+        # read from inside this process); the committed measurement applies to the headline workload only
+        traffic_env = os.environ.get("ISL_TRAFFIC_BYTES")
+        traffic_src = None
+        if not traffic_env and world == 1 and (N, d, nq, ef, k) == (10_000_000, 768, 1024, 128, 10):
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch.json")) as fh:
+                    traffic_env = str(json.load(fh)["search"]["hbm_bytes_per_launch"])
+                    traffic_src = "profiles/r01_pmc_fetch.json (rocprofv3 --pmc FETCH_SIZE x 1024 x 2)"
+            except (OSError, KeyError, ValueError):
+                traffic_env = None
 
-    result = {
-        "metric": "queries/sec @ recall@10>=0.95, 10Mx768 ef=128",
-        "value": round(value, 2),
-        "unit": "queries/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "higher_is_better": True,
-        "scaling": "strong" if (world == 1 or shard_mode) else "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "recall_at_10": round(recall, 4),
-        "config": {
-            "workload": f"{N} x {d} f32 rows resident in HBM (in-memory provider), hierarchical "
-                        f"Gaussian mixture, graph deg<= 60 (mean {gst['deg_mean']:.1f}), "
-                        f"query batch {nq}, k={k}, ef={ef}, cosine",
-            "nodes": N, "dim": d, "query_batch": nq, "k": k, "ef": ef,
-            "parallelism": ("single" if world == 1 else
-                            (f"shard{world}: node-id ranges, RCCL all-gather + top-k merge"
-                             if shard_mode else f"replica{world}")),
-            "searches_in_flight": depth,
-            "per_query": {"expansions": round(agg["expansions"] / max(agg["queries"], 1), 1),
-                          "edges": round(agg["edges"] / max(agg["queries"], 1), 1),
-                          "evals": round(agg["evals"] / max(agg["queries"], 1), 1)},
-            "exact_path_queries": agg["exact_path"], "replayed_queries": agg["replayed"],
-        },
-        "roofline": {
-            # `depth` launches of the search kernel overlap on the chip; the chip-level figure is
-            # the algorithmic bytes of ALL launches of the timed region over its wall time.  The
-            # per-launch figure (bytes of one launch / its own HIP-event duration, the number
-            # rocprofv3 shows per dispatch) is given next to it.
-            "bound": "hbm", "achieved": round(agg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(agg_gbs / HBM_PEAK_GBS, 4),
-            "traffic": float(traffic_env) if traffic_env else None,
-            "traffic_source": traffic_src,
-            "kernel": "leann_search_fast<2,cosine>",
-            "launches_overlapped": depth,
-            "per_launch": {"kernel_ms": round(kernel_ms, 3), "achieved": round(achieved, 1),
-                           "frac": round(achieved / HBM_PEAK_GBS, 4)},
-            "algorithmic_bytes_per_launch": round(bytes_per_launch, 0),
-        },
-    }
+        result = {
+            "metric": "queries/sec @ recall@10>=0.95, 10Mx768 ef=128",
+            "value": round(value, 2),
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong" if (world == 1 or shard_mode) else "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "recall_at_10": round(recall, 4),
+            "config": {
+                "workload": f"{N} x {d} f32 rows resident in HBM (in-memory provider), hierarchical "
+                            f"Gaussian mixture, graph deg<= 60 (mean {gst['deg_mean']:.1f}), "
+                            f"query batch {nq}, k={k}, ef={ef}, cosine",
+                "nodes": N, "dim": d, "query_batch": nq, "k": k, "ef": ef,
+                "parallelism": ("single" if world == 1 else
+                                (f"shard{world}: node-id ranges, RCCL all-gather + top-k merge"
+                                 if shard_mode else f"replica{world}")),
+                "searches_in_flight": depth,
+                "per_query": {"expansions": round(agg["expansions"] / max(agg["queries"], 1), 1),
+                              "edges": round(agg["edges"] / max(agg["queries"], 1), 1),
+                              "evals": round(agg["evals"] / max(agg["queries"], 1), 1)},
+                "exact_path_queries": agg["exact_path"], "replayed_queries": agg["replayed"],
+            },
+            "roofline": {
+                # `depth` launches of the search kernel overlap on the chip; the chip-level figure is
+                # the algorithmic bytes of ALL launches of the timed region over its wall time.  The
+                # per-launch figure (bytes of one launch / its own HIP-event duration, the number
+                # rocprofv3 shows per dispatch) is given next to it.
+                "bound": "hbm", "achieved": round(agg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(agg_gbs / HBM_PEAK_GBS, 4),
+                "traffic": float(traffic_env) if traffic_env else None,
+                "traffic_source": traffic_src,
+                "kernel": "leann_search_fast<2,cosine>",
+                "launches_overlapped": depth,
+                "per_launch": {"kernel_ms": round(kernel_ms, 3), "achieved": round(achieved, 1),
+                               "frac": round(achieved / HBM_PEAK_GBS, 4)},
+                "algorithmic_bytes_per_launch": round(bytes_per_launch, 0),
+            },
+        }
+        return result, (x, offsets, neighbours, entry, qsets)
+
+    result, (x, offsets, neighbours, entry, qsets) = measure(args.mode)
+    if world > 1 and args.mode == "shard" and not args.no_replica:
+        # The 10M x 768 index also fits every GPU whole (30.7 GB of 288 GB): the query-parallel
+        # deployment (full index per GPU, the batches split across ranks, no collective) is
+        # measured next to the sharded one the north star names (SURVEY.md section 8e).
+        del x, offsets, neighbours, qsets
+        torch.cuda.empty_cache()
+        rep, _ = measure("replica")
+        result["replica_mode"] = {k_: rep[k_] for k_ in ("value", "unit", "ms_per_step", "scaling", "recall_at_10")}
+        result["replica_mode"]["parallelism"] = rep["config"]["parallelism"]
+        result["replica_mode"]["roofline_frac_per_gpu"] = rep["roofline"]["frac"]
+        x = offsets = neighbours = entry = qsets = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(x, offsets, neighbours, entry, qsets[0], k, ef)
