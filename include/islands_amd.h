@@ -123,6 +123,30 @@ isl_status isl_index_to_bytes(const isl_index* idx, uint8_t** out, size_t* len);
 void isl_free_bytes(uint8_t* p);
 void isl_index_free(isl_index* idx);
 
+/* ---- storage.rs: IndexMetadata (:16-47) and the chunk framing of IndexWriter / IndexReader ----
+ * A chunk is tag[4] || u64 LE length || payload (:127-135, :159-173); the META chunk carries
+ * serde_json::to_vec(&IndexMetadata) (:119-124).  `now` replaces chrono::Utc::now() (:37). */
+typedef struct isl_index_metadata {
+  uint32_t version;        /* IndexMetadata::CURRENT_VERSION = 1 */
+  uint64_t num_vectors;
+  uint64_t dimension;
+  int64_t created_at;
+  int64_t updated_at;
+  int32_t has_description; /* Option<String> */
+  char description[256];   /* NUL-terminated UTF-8 */
+} isl_index_metadata;
+void isl_index_metadata_new(uint64_t num_vectors, uint64_t dimension, int64_t now, isl_index_metadata* out);
+/* IndexWriter::write_metadata on a buffer: the META chunk (free with isl_free_bytes). */
+isl_status isl_storage_write_metadata(const isl_index_metadata* meta, uint8_t** out, size_t* len);
+/* IndexReader::read_metadata on a buffer; *consumed = bytes of the chunk.  A different tag is
+ * Deserialization("expected META chunk") (:151-153), a short buffer is Io. */
+isl_status isl_storage_read_metadata(const uint8_t* bytes, size_t len, isl_index_metadata* meta,
+                                     size_t* consumed);
+/* One-file persistence: parents created like FileSystemStorage::save (:68-74), chunk META then
+ * chunk "LIDX" = LeannIndex::to_bytes().  meta NULL = IndexMetadata::new(len, dimension) now. */
+isl_status isl_index_save(const isl_index* idx, const char* path, const isl_index_metadata* meta);
+isl_status isl_index_load(const char* path, isl_index** out, isl_index_metadata* meta);
+
 uint64_t isl_index_len(const isl_index* idx);                 /* leann.rs:519-521 */
 int32_t isl_index_is_empty(const isl_index* idx);             /* leann.rs:524-526 */
 int32_t isl_index_dimension(const isl_index* idx, uint64_t* dim); /* 1 = Some, leann.rs:529 */

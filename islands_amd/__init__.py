@@ -10,19 +10,20 @@ from __future__ import annotations
 
 import ctypes as C
 import enum
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
 
 from . import _ffi
-from ._ffi import BertConfigC, LeannConfigC, SearchStatsC
+from ._ffi import BertConfigC, IndexMetadataC, LeannConfigC, SearchStatsC
 
 __all__ = [
     "CoreError", "DistanceMetric", "PruningStrategy", "LeannConfig", "CsrGraph",
     "InMemoryEmbeddingProvider", "LeannIndex", "ProductQuantizer", "SearchResult",
     "batch_calculate", "calculate", "calculate_squared", "normalize_rows", "merge_topk", "merge_service",
     "device_count", "HnswGraph", "SearchConfig", "Searcher", "MultiIndexSearcher",
-    "mean_pool_normalize", "BertConfig", "CandleEmbedder",
+    "mean_pool_normalize", "BertConfig", "CandleEmbedder", "IndexMetadata",
 ]
 
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -286,6 +287,19 @@ class LeannIndex:
         h = C.c_void_p()
         _check(_ffi.lib().isl_index_from_bytes(buf, len(data), C.byref(h)))
         return cls(_handle=h)
+
+    def save(self, path: str, metadata: "IndexMetadata | None" = None) -> None:
+        """One file: chunk META (IndexWriter::write_metadata, storage.rs:119-124) + chunk LIDX
+        (to_bytes); parent directories are created (storage.rs:68-74)."""
+        m = None if metadata is None else metadata._to_c()
+        _check(_ffi.lib().isl_index_save(self._h, os.fsencode(path), None if m is None else C.byref(m)))
+
+    @classmethod
+    def load(cls, path: str) -> "tuple[LeannIndex, IndexMetadata]":
+        h = C.c_void_p()
+        m = IndexMetadataC()
+        _check(_ffi.lib().isl_index_load(os.fsencode(path), C.byref(h), C.byref(m)))
+        return cls(_handle=h), IndexMetadata._from_c(m)
 
     def to_bytes(self) -> bytes:
         """leann.rs:1059-1061"""
@@ -757,6 +771,49 @@ def mean_pool_normalize(hidden, mask, normalize: bool = True, device: int = 0) -
     _check(_ffi.lib().isl_mean_pool_normalize(_ptr(h), _ptr(mk), B, L, H, int(normalize),
                                               _ptr(out), MEM_HOST, device, None))
     return out
+
+
+@dataclass
+class IndexMetadata:
+    """IndexMetadata, src/core/storage.rs:16-47 (`now` replaces chrono::Utc::now())."""
+    version: int = 1
+    num_vectors: int = 0
+    dimension: int = 0
+    created_at: int = 0
+    updated_at: int = 0
+    description: str | None = None
+
+    @classmethod
+    def new(cls, num_vectors: int, dimension: int, now: int) -> "IndexMetadata":
+        m = IndexMetadataC()
+        _ffi.lib().isl_index_metadata_new(num_vectors, dimension, now, C.byref(m))
+        return cls._from_c(m)
+
+    @classmethod
+    def _from_c(cls, m: IndexMetadataC) -> "IndexMetadata":
+        return cls(m.version, m.num_vectors, m.dimension, m.created_at, m.updated_at,
+                   m.description.decode("utf-8") if m.has_description else None)
+
+    def _to_c(self) -> IndexMetadataC:
+        d = (self.description or "").encode("utf-8")
+        return IndexMetadataC(self.version, self.num_vectors, self.dimension, self.created_at,
+                              self.updated_at, int(self.description is not None), d)
+
+    def to_chunk(self) -> bytes:
+        """IndexWriter::write_metadata into a buffer: b"META" + u64 LE length + JSON."""
+        m, p, n = self._to_c(), C.c_void_p(), C.c_size_t()
+        _check(_ffi.lib().isl_storage_write_metadata(C.byref(m), C.byref(p), C.byref(n)))
+        data = C.string_at(p, n.value)
+        _ffi.lib().isl_free_bytes(p)
+        return data
+
+    @classmethod
+    def from_chunk(cls, data: bytes) -> "IndexMetadata":
+        """IndexReader::read_metadata on a buffer."""
+        buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data.ljust(1, b"\0"))
+        m = IndexMetadataC()
+        _check(_ffi.lib().isl_storage_read_metadata(buf, len(data), C.byref(m), None))
+        return cls._from_c(m)
 
 
 @dataclass

@@ -38,6 +38,12 @@ class BertConfigC(C.Structure):
                 ("layer_norm_eps", f32), ("gelu_tanh", u32)]
 
 
+class IndexMetadataC(C.Structure):
+    """isl_index_metadata == IndexMetadata, src/core/storage.rs:16-29."""
+    _fields_ = [("version", u32), ("num_vectors", u64), ("dimension", u64), ("created_at", C.c_int64),
+                ("updated_at", C.c_int64), ("has_description", i32), ("description", C.c_char * 256)]
+
+
 class SearchStatsC(C.Structure):
     _fields_ = [("queries", u64), ("expansions", u64), ("edges", u64), ("evals", u64),
                 ("pushes", u64), ("exact_path", u64), ("replayed", u64), ("kernel_ms", C.c_double),
@@ -98,6 +104,11 @@ SIGNATURES = {
     "isl_merge_service": (i32, [u64, u64, u64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u64,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, i32, i32,
                              C.c_void_p]),
+    "isl_index_metadata_new": (None, [u64, u64, C.c_int64, P(IndexMetadataC)]),
+    "isl_storage_write_metadata": (i32, [P(IndexMetadataC), P(C.c_void_p), P(C.c_size_t)]),
+    "isl_storage_read_metadata": (i32, [C.c_void_p, C.c_size_t, P(IndexMetadataC), P(C.c_size_t)]),
+    "isl_index_save": (i32, [C.c_void_p, C.c_char_p, P(IndexMetadataC)]),
+    "isl_index_load": (i32, [C.c_char_p, P(C.c_void_p), P(IndexMetadataC)]),
     "isl_encoder_new": (i32, [P(BertConfigC), i32, P(C.c_void_p)]),
     "isl_encoder_free": (None, [C.c_void_p]),
     "isl_encoder_set_weight": (i32, [C.c_void_p, C.c_char_p, C.c_void_p, u64, i32]),
