@@ -117,6 +117,16 @@ isl_status isl_index_from_device_csr(const isl_leann_config* cfg, int32_t device
                                      const uint32_t* d_neighbors, int32_t has_entry,
                                      uint64_t entry_point, int32_t has_dimension,
                                      uint64_t dimension, isl_index** out);
+/* LeannIndex::build, leann.rs:560-630, on the device: insertion in id order, construction
+ * search with ef_construction (:692-749), high-degree-preserving selection (:761-833) or
+ * truncation (:685), bidirectional links with a distance re-sort past m0 (:592-607, :634-658).
+ * `levels` replaces random_level (thread_rng, :549-554; NULL = all 0).  `batch` = nodes inserted
+ * per step: 1 reproduces the reference's sequential construction (CsrGraph identical field by
+ * field), larger values trade that for throughput.  The vectors become the index's in-memory
+ * provider.  Limits: m0 <= 63, ef_construction <= 512. */
+isl_status isl_index_build(const isl_leann_config* cfg, const float* vectors, uint64_t n, uint64_t d,
+                           const uint64_t* levels, uint64_t batch, int32_t mem, int32_t device,
+                           isl_index** out);
 /* LeannIndex::from_bytes / to_bytes, leann.rs:1059-1066 (bincode 1.x default layout). */
 isl_status isl_index_from_bytes(const uint8_t* bytes, size_t len, isl_index** out);
 isl_status isl_index_to_bytes(const isl_index* idx, uint8_t** out, size_t* len);

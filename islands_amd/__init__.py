@@ -269,6 +269,22 @@ class LeannIndex:
         return cls(_handle=h)
 
     @classmethod
+    def build(cls, vectors, config: LeannConfig | None = None, levels=None, batch: int = 1,
+              device: int = 0) -> "LeannIndex":
+        """LeannIndex::build (leann.rs:560-630) on the device; `levels` replaces random_level
+        (thread_rng); batch = 1 is the reference's sequential insertion, larger batches insert
+        that many nodes per step.  The vectors become the in-memory provider."""
+        v = _f32(vectors)
+        n, d = v.shape if v.ndim == 2 else (0, 0)
+        c = (config or LeannConfig())._to_c()
+        lv = None if levels is None else np.ascontiguousarray(levels, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(_ffi.lib().isl_index_build(C.byref(c), _ptr(v) if n else None, n, d,
+                                          None if lv is None else _ptr(lv), batch, MEM_HOST, device,
+                                          C.byref(h)))
+        return cls(_handle=h)
+
+    @classmethod
     def from_device_csr(cls, d_offsets_ptr: int, d_neighbors_ptr: int, num_nodes: int,
                         entry_point: int | None, dimension: int | None,
                         config: LeannConfig | None = None, device: int = 0) -> "LeannIndex":

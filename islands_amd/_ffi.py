@@ -104,6 +104,8 @@ SIGNATURES = {
     "isl_merge_service": (i32, [u64, u64, u64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u64,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, i32, i32,
                              C.c_void_p]),
+    "isl_index_build": (i32, [P(LeannConfigC), C.c_void_p, u64, u64, C.c_void_p, u64, i32, i32,
+                              P(C.c_void_p)]),
     "isl_index_metadata_new": (None, [u64, u64, C.c_int64, P(IndexMetadataC)]),
     "isl_storage_write_metadata": (i32, [P(IndexMetadataC), P(C.c_void_p), P(C.c_size_t)]),
     "isl_storage_read_metadata": (i32, [C.c_void_p, C.c_size_t, P(IndexMetadataC), P(C.c_size_t)]),

@@ -499,7 +499,7 @@ isl_status materialise_host_csr(const isl_index* cidx) {
   if (idx->nnz)
     ISL_HIP(hipMemcpy(tmp.data(), idx->d_adj, idx->nnz * 4, hipMemcpyDeviceToHost));
   idx->neighbors.assign(tmp.begin(), tmp.end());
-  idx->levels.assign(idx->num_nodes, 0);
+  if (idx->levels.size() != idx->num_nodes) idx->levels.assign(idx->num_nodes, 0);
   idx->degree_counts.resize(idx->num_nodes);
   for (uint64_t i = 0; i < idx->num_nodes; i++)
     idx->degree_counts[i] = idx->node_offsets[i + 1] - idx->node_offsets[i];

@@ -124,6 +124,11 @@ struct isl_index {
   float* d_norm2 = nullptr;  // [nvec] sum of squares of every row, reference summation order
   uint64_t nvec = 0, emb_d = 0, emb_stride = 0;
 
+  // graph under construction (build.hip): fixed-width adjacency rows, searched in place
+  uint32_t* d_ell = nullptr;      // [num_nodes][ell_w]
+  uint32_t* d_ell_deg = nullptr;  // [num_nodes]
+  uint32_t ell_w = 0;
+
   // recompute provider (EmbeddingProvider backed by the encoder, leann.rs:82-99): rows of d_emb
   // exist only where d_present has a bit; the search reports the rows it misses and the
   // provider encodes them from the resident token table
@@ -150,6 +155,11 @@ struct isl_index {
 };
 
 namespace isl {
+// One synchronous search over device buffers on a free lane (no argument checks): the path
+// isl_search_batch_device takes, used by the graph builder for its construction searches.
+isl_status search_device_sync(const isl_index* idx, const float* d_queries, uint64_t nq, uint64_t d,
+                              uint64_t k, uint64_t ef, uint64_t* d_ids, float* d_dist,
+                              uint32_t* d_count, hipStream_t stream);
 isl_status materialise_host_csr(const isl_index* idx);
 void free_workspace(SearchWorkspace& ws);
 }  // namespace isl

@@ -86,6 +86,9 @@ struct SearchParams {
   uint64_t vis_words;
   uint32_t* ulist;
   uint32_t ulist_cap;
+  // graph under construction (build.hip): row i = adj[i * ell_w .. + ell_deg[i]), `off` unused
+  uint32_t ell_w;
+  const uint32_t* ell_deg;
   // recompute provider: rows exist where `present` has a bit; a query that needs an absent row
   // appends the id to `miss` (count in ticket[13]) and stops with QS_BLOCKED
   const uint32_t* present;
@@ -502,7 +505,10 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
         break;
       }
       if ((uint64_t)cid >= p.num_nodes) continue;  // get_neighbors -> None, leann.rs:227-229
-      uint64_t o0 = p.off[cid], o1 = p.off[cid + 1];
+      // adjacency: CSR, or fixed-width rows while the graph is under construction (build.hip)
+      uint64_t o0, o1;
+      if (p.ell_w) { o0 = (uint64_t)cid * p.ell_w; o1 = o0 + p.ell_deg[cid]; }
+      else { o0 = p.off[cid]; o1 = p.off[cid + 1]; }
       uint32_t deg = (uint32_t)(o1 - o0);
       cH += 1;
       cE += deg;
@@ -830,7 +836,9 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
       __syncthreads();
       if (!go) break;
       if ((uint64_t)cid >= p.num_nodes) continue;
-      uint64_t o0 = p.off[cid], o1 = p.off[cid + 1];
+      uint64_t o0, o1;
+      if (p.ell_w) { o0 = (uint64_t)cid * p.ell_w; o1 = o0 + p.ell_deg[cid]; }
+      else { o0 = p.off[cid]; o1 = p.off[cid + 1]; }
       uint32_t deg = (uint32_t)(o1 - o0);
       cH += 1;
       cE += deg;
@@ -1183,7 +1191,9 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
 
   SearchParams p{};
   p.off = idx->d_off;
-  p.adj = idx->d_adj;
+  p.adj = idx->d_ell ? idx->d_ell : idx->d_adj;
+  p.ell_w = idx->d_ell ? idx->ell_w : 0u;
+  p.ell_deg = idx->d_ell_deg;
   p.num_nodes = idx->num_nodes;
   p.emb = idx->d_emb;
   p.norm2 = idx->d_norm2;
@@ -1608,3 +1618,14 @@ isl_status isl_search_last_stats(const isl_index* idx, isl_search_stats* out) {
 }
 
 }  // extern "C"
+
+namespace isl {
+isl_status search_device_sync(const isl_index* idx, const float* d_queries, uint64_t nq, uint64_t d,
+                              uint64_t k, uint64_t ef, uint64_t* d_ids, float* d_dist,
+                              uint32_t* d_count, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(idx->mu);
+  isl::SearchWorkspace* ws = free_lane(idx);
+  if (!ws) return isl::fail(ISL_ERR_SEARCH, "Search error: every search lane has a call in flight");
+  return search_sync(idx, *ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, stream, StreamMode::USER);
+}
+}  // namespace isl

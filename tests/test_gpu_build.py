@@ -1,0 +1,86 @@
+"""GPU: LeannIndex::build on the device (isl_index_build) against the oracle's restatement of
+the reference builder (leann.rs:560-833).  With batch = 1 the construction is the reference's
+sequential one: the whole LeannIndex must serialise to the same bytes (config, node_offsets,
+neighbors, levels, entry_point, max_level, degree_counts, dimension)."""
+import numpy as np
+import pytest
+
+import islands_amd as ia
+from _data import clustered_vectors, random_levels, uniform_vectors
+
+pytestmark = pytest.mark.gpu
+
+
+def reference_bytes(orc, v, cfg, levels):
+    csr = orc.leann_build(v, m=cfg.m, m0=cfg.m0, ef_construction=cfg.ef_construction,
+                          metric=int(cfg.metric), high_degree_pruning=cfg.high_degree_pruning,
+                          hub_percentile=cfg.hub_percentile, levels=levels)
+    g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels,
+                    entry_point=csr.entry_point, max_level=csr.max_level, num_nodes=csr.num_nodes,
+                    degree_counts=csr.degree_counts)
+    return ia.LeannIndex.from_csr(g, cfg, dimension=v.shape[1]).to_bytes(), csr
+
+
+@pytest.mark.parametrize("metric", [ia.DistanceMetric.Cosine, ia.DistanceMetric.Euclidean,
+                                    ia.DistanceMetric.DotProduct, ia.DistanceMetric.Manhattan])
+def test_sequential_build_is_the_reference_graph(orc, metric):
+    n, d = 500, 24
+    v = clustered_vectors(n, d, 7)
+    cfg = ia.LeannConfig(m=8, m0=16, ef_construction=40, metric=metric)
+    levels = random_levels(n, 8, 3)
+    want, _ = reference_bytes(orc, v, cfg, levels)
+    idx = ia.LeannIndex.build(v, cfg, levels=levels, batch=1)
+    assert idx.to_bytes() == want
+
+
+@pytest.mark.parametrize("hub_percentile,high_degree", [(0.02, True), (0.25, True), (0.02, False)])
+def test_hub_rule_variants(orc, hub_percentile, high_degree):
+    n, d = 700, 16
+    v = uniform_vectors(n, d, 11)
+    cfg = ia.LeannConfig(m=6, m0=12, ef_construction=48, hub_percentile=hub_percentile,
+                         high_degree_pruning=high_degree)
+    want, csr = reference_bytes(orc, v, cfg, None)
+    idx = ia.LeannIndex.build(v, cfg, batch=1)
+    assert idx.to_bytes() == want
+    # and the built index answers like the oracle's search over the oracle's graph
+    q = uniform_vectors(12, d, 12)
+    ids, dist, cnt = idx.search_batch(q, 5, 30)
+    for i in range(12):
+        r = orc.leann_search(csr, v, q[i], 5, 30)
+        assert ids[i, :cnt[i]].tolist() == r.ids.tolist()
+        assert dist[i, :cnt[i]].view(np.uint32).tolist() == r.dist.view(np.uint32).tolist()
+
+
+def test_paper_default_config_and_duplicates(orc):  # leann.rs:1437-1464 shapes; equal rows tie everywhere
+    base = uniform_vectors(150, 32, 5)
+    v = np.concatenate([base, base[:60]]).astype(np.float32)
+    cfg = ia.LeannConfig.paper_default()  # m0 = 60, ef_construction = 128
+    want, _ = reference_bytes(orc, v, cfg, None)
+    assert ia.LeannIndex.build(v, cfg, batch=1).to_bytes() == want
+
+
+def test_batched_build_keeps_the_invariants(orc):
+    n, d = 3000, 16
+    v = uniform_vectors(n, d, 21)  # the reference builder itself reaches recall@1 = 1.0 here
+    cfg = ia.LeannConfig(m=8, m0=16, ef_construction=64)
+    idx = ia.LeannIndex.build(v, cfg, batch=256)
+    assert len(idx) == n and idx.dimension() == d and idx.entry_point == 0
+    degs = [len(idx.get_neighbors(i)) for i in range(n)]
+    assert max(degs) <= 16 and min(degs[1:]) >= 1
+    for i in (1, 17, n - 1):
+        nb = idx.get_neighbors(i).tolist()
+        assert len(set(nb)) == len(nb) and i not in nb
+    # recall@1 of self-queries, like leann.rs:1388-1433 (>= 0.35 there)
+    q = v[::30]
+    ids, dist, cnt = idx.search_batch(q, 1, 64)
+    assert (ids[:, 0] == np.arange(0, n, 30)).mean() >= 0.9
+
+
+def test_build_edge_cases():
+    e = ia.LeannIndex.build(np.zeros((0, 0), np.float32))
+    assert e.is_empty()
+    one = ia.LeannIndex.build(np.ones((1, 8), np.float32))
+    assert len(one) == 1 and one.entry_point == 0 and one.search(np.ones(8, np.float32), 3)[0][0] == 0
+    with pytest.raises(ia.CoreError) as ex:
+        ia.LeannIndex.build(np.ones((4, 8), np.float32), ia.LeannConfig.accurate())  # m0 = 96
+    assert ex.value.kind == "Unsupported"
