@@ -245,6 +245,21 @@ isl_status isl_distance_batch(int32_t metric, const float* query, uint64_t d, co
 isl_status isl_normalize_rows(float* rows, uint64_t n, uint64_t d, int32_t mem, int32_t device,
                               void* stream);
 
+/* Every (query, row) distance at once as one GEMM on the matrix cores (float32 MFMA): the
+ * batch_calculate of distance.rs:32-34 / benches/vector_ops.rs:60-79 for a whole query batch.
+ * out [nq][n].  Cosine, Euclidean (sqrt(|q|^2 + |r|^2 - 2 q.r), clamped at 0) and DotProduct;
+ * Manhattan is not a contraction (Unsupported).  The MFMA accumulates in its own order: values
+ * agree with the sequential reference sums to float32 rounding, not bit for bit -- the search
+ * itself keeps the exact-order kernels. */
+isl_status isl_distance_matrix(int32_t metric, const float* queries, uint64_t nq, const float* rows,
+                               uint64_t n, uint64_t d, float* out, int32_t mem, int32_t device,
+                               void* stream);
+/* Exact k nearest rows of every query by brute force over isl_distance_matrix blocks (ties
+ * towards the smaller id): the ground truth of recall measurements. */
+isl_status isl_bruteforce_topk(int32_t metric, const float* queries, uint64_t nq, const float* rows,
+                               uint64_t n, uint64_t d, uint64_t k, uint64_t* out_ids, float* out_dist,
+                               uint32_t* out_count, int32_t mem, int32_t device, void* stream);
+
 /* ---- search.rs / indexer merge (multi-index = multi-shard) ---- */
 /* MultiIndexSearcher::search merge, search.rs:211-237: per query, nlists
  * candidate lists (list-major: [list][query][k]) concatenated in list order,

@@ -21,7 +21,8 @@ from ._ffi import BertConfigC, IndexMetadataC, LeannConfigC, SearchStatsC
 __all__ = [
     "CoreError", "DistanceMetric", "PruningStrategy", "LeannConfig", "CsrGraph",
     "InMemoryEmbeddingProvider", "LeannIndex", "ProductQuantizer", "SearchResult",
-    "batch_calculate", "calculate", "calculate_squared", "normalize_rows", "merge_topk", "merge_service",
+    "batch_calculate", "calculate", "calculate_squared", "normalize_rows", "distance_matrix",
+    "bruteforce_topk", "merge_topk", "merge_service",
     "device_count", "HnswGraph", "SearchConfig", "Searcher", "MultiIndexSearcher",
     "mean_pool_normalize", "BertConfig", "CandleEmbedder", "IndexMetadata",
 ]
@@ -102,6 +103,27 @@ def batch_calculate(metric: DistanceMetric, query, vectors, device: int = 0) -> 
     _check(_ffi.lib().isl_distance_batch(int(metric), _ptr(q), q.size, _ptr(v), n, row_len,
                                          _ptr(out), MEM_HOST, device, None))
     return out
+
+
+def distance_matrix(metric: DistanceMetric, queries, rows, device: int = 0) -> np.ndarray:
+    """All query x row distances as one float32 GEMM on the matrix cores -> [nq, n]."""
+    q, r = _f32(queries), _f32(rows)
+    out = np.zeros((q.shape[0], r.shape[0]), dtype=np.float32)
+    _check(_ffi.lib().isl_distance_matrix(int(metric), _ptr(q), q.shape[0], _ptr(r), r.shape[0],
+                                          q.shape[1], _ptr(out), MEM_HOST, device, None))
+    return out
+
+
+def bruteforce_topk(metric: DistanceMetric, queries, rows, k: int, device: int = 0):
+    """Exact k nearest rows per query (ids, distances, counts), ties towards the smaller id."""
+    q, r = _f32(queries), _f32(rows)
+    nq = q.shape[0]
+    ids = np.zeros((nq, max(k, 1)), dtype=np.uint64)
+    dd = np.zeros((nq, max(k, 1)), dtype=np.float32)
+    cnt = np.zeros(nq, dtype=np.uint32)
+    _check(_ffi.lib().isl_bruteforce_topk(int(metric), _ptr(q), nq, _ptr(r), r.shape[0], q.shape[1], k,
+                                          _ptr(ids), _ptr(dd), _ptr(cnt), MEM_HOST, device, None))
+    return ids[:, :k], dd[:, :k], cnt
 
 
 def normalize_rows(rows, device: int = 0) -> np.ndarray:

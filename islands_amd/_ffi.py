@@ -98,6 +98,10 @@ SIGNATURES = {
     "isl_distance_batch": (i32, [i32, C.c_void_p, u64, C.c_void_p, u64, u64, C.c_void_p, i32, i32,
                                  C.c_void_p]),
     "isl_normalize_rows": (i32, [C.c_void_p, u64, u64, i32, i32, C.c_void_p]),
+    "isl_distance_matrix": (i32, [i32, C.c_void_p, u64, C.c_void_p, u64, u64, C.c_void_p, i32, i32,
+                                  C.c_void_p]),
+    "isl_bruteforce_topk": (i32, [i32, C.c_void_p, u64, C.c_void_p, u64, u64, u64, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, i32, i32, C.c_void_p]),
     "isl_merge_topk": (i32, [u64, u64, u64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u64,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, i32, i32,
                              C.c_void_p]),

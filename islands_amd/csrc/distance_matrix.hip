@@ -1,0 +1,199 @@
+// Batched distances as a query x candidate GEMM on the matrix cores: every (query, row) pair of
+// Distance::batch_calculate (src/core/distance.rs:32-34, benches/vector_ops.rs:60-79) at once,
+// and exact brute-force top-k on top of it (the ground truth of the recall measurement).
+// The dot products come out of v_mfma_f32_32x32x2_f32 in the MFMA's accumulation order, so the
+// values agree with the reference's sequential sums to float32 rounding (<= 1e-5 on normalised
+// rows), not bit for bit -- the traversal keeps the exact-order kernels.
+#include "device_common.cuh"
+#include "gemm_f32.cuh"
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+using namespace isl_gemm;
+
+// sum of squares of every row (one wave per row)
+__global__ __launch_bounds__(64) void sumsq_rows_kernel(const float* __restrict__ x, uint64_t n, uint32_t d,
+                                                        uint64_t stride, float* __restrict__ out) {
+  const uint64_t row = blockIdx.x;
+  if (row >= n) return;
+  float s = 0.0f;
+  for (uint32_t j = threadIdx.x; j < d; j += 64) { float v = x[row * stride + j]; s += v * v; }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  if (threadIdx.x == 0) out[row] = s;
+}
+
+// Keeps the k smallest (distance, id) of every query across column chunks: one wave per query,
+// the running list sorted ascending in LDS, ties resolved towards the smaller id.
+__global__ __launch_bounds__(64) void topk_chunk_kernel(const float* __restrict__ dist, uint64_t ld,
+                                                        uint32_t cols, uint64_t col0, uint32_t k,
+                                                        float* __restrict__ best_d, uint64_t* __restrict__ best_i,
+                                                        uint32_t* __restrict__ best_n) {
+  extern __shared__ unsigned char sm[];
+  float* bd = reinterpret_cast<float*>(sm);
+  uint64_t* bi = reinterpret_cast<uint64_t*>(sm + ((k * 4 + 7) & ~7u));
+  const uint32_t q = blockIdx.x, lane = threadIdx.x;
+  uint32_t cnt = best_n[q];
+  for (uint32_t i = lane; i < cnt; i += 64) { bd[i] = best_d[(uint64_t)q * k + i]; bi[i] = best_i[(uint64_t)q * k + i]; }
+  __syncthreads();
+  const float* row = dist + (uint64_t)q * ld;
+  for (uint32_t c0 = 0; c0 < cols; c0 += 64) {
+    const uint32_t c = c0 + lane;
+    const float v = c < cols ? row[c] : 0.0f;
+    const float kth = cnt == k ? bd[k - 1] : 0.0f;
+    const bool cand = c < cols && (cnt < k || v < kth || (v == kth && col0 + c < bi[k - 1]));
+    uint64_t m = __ballot(cand);
+    while (m) {
+      const int l = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const float nv = __shfl(v, l);
+      const uint64_t ni = col0 + c0 + (uint32_t)l;
+      if (lane == 0) {
+        if (cnt == k && !(nv < bd[k - 1] || (nv == bd[k - 1] && ni < bi[k - 1]))) {
+          // no longer among the k best
+        } else {
+          uint32_t pos = cnt < k ? cnt : k - 1;
+          while (pos > 0 && (nv < bd[pos - 1] || (nv == bd[pos - 1] && ni < bi[pos - 1]))) {
+            bd[pos] = bd[pos - 1];
+            bi[pos] = bi[pos - 1];
+            --pos;
+          }
+          bd[pos] = nv;
+          bi[pos] = ni;
+          if (cnt < k) ++cnt;
+        }
+      }
+      cnt = (uint32_t)__shfl((int)cnt, 0);
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = lane; i < cnt; i += 64) { best_d[(uint64_t)q * k + i] = bd[i]; best_i[(uint64_t)q * k + i] = bi[i]; }
+  if (lane == 0) best_n[q] = cnt;
+}
+
+struct Staged {
+  std::vector<void*> owned;
+  ~Staged() { for (void* p : owned) (void)hipFree(p); }
+  void* alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return nullptr;
+    owned.push_back(p);
+    return p;
+  }
+};
+
+// device copy of a [n][d] matrix with rows padded to a multiple of 4 floats (GEMM loads 16 B)
+isl_status stage_matrix(Staged& s, const float* src, uint64_t n, uint64_t d, int32_t mem, hipStream_t st,
+                        const float** out, uint64_t* stride) {
+  const uint64_t ld = (d + 3) / 4 * 4;
+  *stride = ld;
+  if (mem == ISL_MEM_DEVICE && ld == d) { *out = src; return ISL_OK; }
+  float* p = (float*)s.alloc(n * ld * 4);
+  if (!p) return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed");
+  if (ld != d) ISL_HIP(hipMemsetAsync(p, 0, n * ld * 4, st));
+  ISL_HIP(hipMemcpy2DAsync(p, ld * 4, src, d * 4, d * 4, n,
+                           mem == ISL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  *out = p;
+  return ISL_OK;
+}
+
+isl_status launch_distance_gemm(int32_t metric, const float* dq, const float* dr, const float* qn,
+                                const float* rn, float* dout, uint64_t nq, uint64_t n, uint64_t ld,
+                                hipStream_t st) {
+  switch (metric) {
+    case ISL_METRIC_COSINE: launch_gemm<EPI_COSINE, false>(dq, dr, rn, qn, dout, nq, n, ld, st); break;
+    case ISL_METRIC_DOT: launch_gemm<EPI_DOT, false>(dq, dr, nullptr, nullptr, dout, nq, n, ld, st); break;
+    case ISL_METRIC_EUCLIDEAN: launch_gemm<EPI_EUCLIDEAN, false>(dq, dr, rn, qn, dout, nq, n, ld, st); break;
+    default:
+      return isl::fail(ISL_ERR_UNSUPPORTED, "the Manhattan distance is not a contraction: use isl_distance_batch");
+  }
+  ISL_HIP(hipGetLastError());
+  return ISL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+isl_status isl_distance_matrix(int32_t metric, const float* queries, uint64_t nq, const float* rows,
+                               uint64_t n, uint64_t d, float* out, int32_t mem, int32_t device,
+                               void* stream) {
+  if (nq == 0 || n == 0) return ISL_OK;
+  if (!queries || !rows || !out) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
+  if (d == 0) return isl::fail(ISL_ERR_EMPTY_COLLECTION, "Empty vector collection");
+  if (nq > 0xFFFFFFFFull || n > 0xFFFFFFFFull) return isl::fail(ISL_ERR_UNSUPPORTED, "matrix side above 2^32");
+  ISL_TRY(isl::use_device(device));
+  hipStream_t st = (hipStream_t)stream;
+  Staged s;
+  const float *dq, *dr;
+  uint64_t ldq, ldr;
+  ISL_TRY(stage_matrix(s, queries, nq, d, mem, st, &dq, &ldq));
+  ISL_TRY(stage_matrix(s, rows, n, d, mem, st, &dr, &ldr));
+  float* qn = (float*)s.alloc(nq * 4);
+  float* rn = (float*)s.alloc(n * 4);
+  float* dout = mem == ISL_MEM_DEVICE ? out : (float*)s.alloc(nq * n * 4);
+  if (!qn || !rn || !dout) return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed");
+  hipLaunchKernelGGL(sumsq_rows_kernel, dim3((uint32_t)nq), dim3(64), 0, st, dq, nq, (uint32_t)d, ldq, qn);
+  hipLaunchKernelGGL(sumsq_rows_kernel, dim3((uint32_t)n), dim3(64), 0, st, dr, n, (uint32_t)d, ldr, rn);
+  ISL_TRY(launch_distance_gemm(metric, dq, dr, qn, rn, dout, nq, n, ldq, st));
+  if (mem == ISL_MEM_HOST) ISL_HIP(hipMemcpyAsync(out, dout, nq * n * 4, hipMemcpyDeviceToHost, st));
+  ISL_HIP(hipStreamSynchronize(st));
+  return ISL_OK;
+}
+
+isl_status isl_bruteforce_topk(int32_t metric, const float* queries, uint64_t nq, const float* rows,
+                               uint64_t n, uint64_t d, uint64_t k, uint64_t* out_ids, float* out_dist,
+                               uint32_t* out_count, int32_t mem, int32_t device, void* stream) {
+  if (nq == 0) return ISL_OK;
+  if (!queries || !out_count || (k && (!out_ids || !out_dist)) || (!rows && n))
+    return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
+  if (k > 1024) return isl::fail(ISL_ERR_UNSUPPORTED, "k <= 1024");
+  if (nq > 0xFFFFFFFFull) return isl::fail(ISL_ERR_UNSUPPORTED, "too many queries");
+  ISL_TRY(isl::use_device(device));
+  hipStream_t st = (hipStream_t)stream;
+  Staged s;
+  const uint64_t kk = k ? k : 1;
+  float* bd = (float*)s.alloc(nq * kk * 4);
+  uint64_t* bi = (uint64_t*)s.alloc(nq * kk * 8);
+  uint32_t* bn = (uint32_t*)s.alloc(nq * 4);
+  if (!bd || !bi || !bn) return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed");
+  ISL_HIP(hipMemsetAsync(bn, 0, nq * 4, st));
+  if (n && k && d) {
+    const float *dq, *dr;
+    uint64_t ldq, ldr;
+    ISL_TRY(stage_matrix(s, queries, nq, d, mem, st, &dq, &ldq));
+    ISL_TRY(stage_matrix(s, rows, n, d, mem, st, &dr, &ldr));
+    // column chunks sized so that the distance block stays near 1 GiB
+    const uint64_t chunk = std::max<uint64_t>(4096, std::min<uint64_t>(n, (1ull << 28) / std::max<uint64_t>(nq, 1)));
+    float* qn = (float*)s.alloc(nq * 4);
+    float* rn = (float*)s.alloc(n * 4);
+    float* blk = (float*)s.alloc(nq * chunk * 4);
+    if (!qn || !rn || !blk) return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed");
+    hipLaunchKernelGGL(sumsq_rows_kernel, dim3((uint32_t)nq), dim3(64), 0, st, dq, nq, (uint32_t)d, ldq, qn);
+    for (uint64_t r0 = 0; r0 < n; r0 += 0x7FFFFFFFull)  // grid.x limit
+      hipLaunchKernelGGL(sumsq_rows_kernel, dim3((uint32_t)std::min<uint64_t>(n - r0, 0x7FFFFFFFull)), dim3(64), 0,
+                         st, dr + r0 * ldr, n - r0, (uint32_t)d, ldr, rn + r0);
+    const size_t lds = ((kk * 4 + 7) & ~7ull) + kk * 8;
+    for (uint64_t c0 = 0; c0 < n; c0 += chunk) {
+      const uint64_t cols = std::min(chunk, n - c0);
+      ISL_TRY(launch_distance_gemm(metric, dq, dr + c0 * ldr, qn, rn + c0, blk, nq, cols, ldq, st));
+      hipLaunchKernelGGL(topk_chunk_kernel, dim3((uint32_t)nq), dim3(64), lds, st, blk, cols, (uint32_t)cols, c0,
+                         (uint32_t)k, bd, bi, bn);
+    }
+    ISL_HIP(hipGetLastError());
+  }
+  hipMemcpyKind kind = mem == ISL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (k) {
+    ISL_HIP(hipMemcpyAsync(out_ids, bi, nq * k * 8, kind, st));
+    ISL_HIP(hipMemcpyAsync(out_dist, bd, nq * k * 4, kind, st));
+  }
+  ISL_HIP(hipMemcpyAsync(out_count, bn, nq * 4, kind, st));
+  ISL_HIP(hipStreamSynchronize(st));
+  return ISL_OK;
+}
+
+}  // extern "C"

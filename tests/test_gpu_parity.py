@@ -327,3 +327,45 @@ def test_pq_matches_oracle(orc):  # pq.rs:639-677, 787-809, 505-520
     with pytest.raises(ia.CoreError) as e:
         pq8.build_distance_tables(np.zeros(64, np.float32))
     assert e.value.kind == "DimensionMismatch"
+
+
+# ------------------------------------------------ distance matrix on the matrix cores
+@pytest.mark.parametrize("metric", [ia.DistanceMetric.Cosine, ia.DistanceMetric.DotProduct,
+                                    ia.DistanceMetric.Euclidean])
+@pytest.mark.parametrize("nq,n,d", [(5, 300, 128), (130, 257, 768), (3, 70, 30)])
+def test_distance_matrix_matches_batch_calculate(orc, metric, nq, n, d):
+    """float32 MFMA accumulation vs the reference's sequential sums: 1e-5 on normalised rows
+    (north star tolerance); the Euclidean form |q|^2 + |r|^2 - 2 q.r loses digits near zero, so
+    it is compared on the squared distance."""
+    rows = clustered_vectors(n, d, 3)
+    q = clustered_vectors(nq, d, 4)
+    got = ia.distance_matrix(metric, q, rows)
+    for i in range(nq):
+        want = orc.batch_distance(int(metric), q[i], rows)
+        if metric == ia.DistanceMetric.Euclidean:
+            assert np.abs(got[i] ** 2 - want ** 2).max() < 1e-5
+        else:
+            assert np.abs(got[i] - want).max() < 1e-5
+    with pytest.raises(ia.CoreError) as e:
+        ia.distance_matrix(ia.DistanceMetric.Manhattan, q, rows)
+    assert e.value.kind == "Unsupported"
+
+
+def test_bruteforce_topk(orc):
+    n, d, nq, k = 5000, 64, 37, 10
+    rows = clustered_vectors(n, d, 8)
+    q = clustered_vectors(nq, d, 9)
+    ids, dist, cnt = ia.bruteforce_topk(ia.DistanceMetric.Cosine, q, rows, k)
+    assert (cnt == k).all()
+    for i in range(nq):
+        exact = orc.batch_distance(orc.COSINE, q[i], rows)
+        order = np.argsort(exact, kind="stable")
+        assert np.abs(dist[i] - exact[order[:k]]).max() < 1e-5
+        assert np.all(np.diff(dist[i]) >= 0)
+        # same ids wherever the next distance is not within rounding of this one
+        gaps = np.diff(exact[order[:k + 1]])
+        for j in range(k):
+            if (j == 0 or gaps[j - 1] > 1e-5) and gaps[j] > 1e-5:
+                assert ids[i, j] == order[j]
+    few = ia.bruteforce_topk(ia.DistanceMetric.DotProduct, q[:2], rows[:4], 10)
+    assert few[2].tolist() == [4, 4]
