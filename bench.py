@@ -190,7 +190,7 @@ def main():
             qoff = (b + (rank * nb_batches if (world > 1 and not shard_mode) else 0)) * nq
             q = synth.make_rows(N, d, qoff, nq, per_cluster=args.per_cluster, device=dev, query=True)
             qsets.append(q.contiguous())
-            ti, td = synth.brute_force_topk(x, q, k)
+            ti, td = synth.brute_force_topk_native(x, q, k)  # exact truth: float32 MFMA brute force
             truths.append((ti + lo, td))
         torch.cuda.synchronize()
 

@@ -118,6 +118,25 @@ def brute_force_topk(x: torch.Tensor, q: torch.Tensor, k: int, metric: str = "co
     return best_i, best_d
 
 
+def brute_force_topk_native(x: torch.Tensor, q: torch.Tensor, k: int, metric: int = 0):
+    """Exact top-k through the library's own brute force (isl_bruteforce_topk: float32 MFMA
+    distance blocks + a running top-k), device buffers in and out."""
+    import ctypes as C
+
+    from . import _check, _ffi
+    nq = q.shape[0]
+    x, q = x.contiguous(), q.contiguous()
+    ids = torch.zeros((nq, k), dtype=torch.int64, device=x.device)
+    dd = torch.zeros((nq, k), dtype=torch.float32, device=x.device)
+    cnt = torch.zeros(nq, dtype=torch.int32, device=x.device)
+    torch.cuda.synchronize(x.device)
+    _check(_ffi.lib().isl_bruteforce_topk(
+        metric, C.c_void_p(q.data_ptr()), nq, C.c_void_p(x.data_ptr()), x.shape[0], x.shape[1], k,
+        C.c_void_p(ids.data_ptr()), C.c_void_p(dd.data_ptr()), C.c_void_p(cnt.data_ptr()), 1,
+        x.device.index or 0, None))
+    return ids, dd
+
+
 def recall_at_k(found_ids: torch.Tensor, found_cnt: torch.Tensor, truth_ids: torch.Tensor) -> float:
     k = truth_ids.shape[1]
     f = found_ids[:, :k].to(torch.int64)
