@@ -379,6 +379,9 @@ uint64_t isl_hnsw_len(const isl_hnsw* h);
 isl_status isl_hnsw_search_batch(const isl_hnsw* h, const float* queries, uint64_t nq, uint64_t d,
                                  uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dist,
                                  uint32_t* out_count);
+/* Work counters of the most recent search on this graph (see isl_search_last_stats);
+ * exact_path = queries in which two equal distances met and the heap-exact kernel decided. */
+isl_status isl_hnsw_last_stats(const isl_hnsw* h, isl_search_stats* out);
 
 #ifdef __cplusplus
 }

@@ -651,6 +651,11 @@ class HnswGraph:
     def is_empty(self) -> bool:
         return len(self) == 0
 
+    def last_stats(self) -> dict:
+        s = SearchStatsC()
+        _check(_ffi.lib().isl_hnsw_last_stats(self._h, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in SearchStatsC._fields_}
+
     def get_vector(self, node: int):
         """get_node(id).vector, hnsw.rs:507-510"""
         return self.vectors[node] if 0 <= node < self.vectors.shape[0] else None

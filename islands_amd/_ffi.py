@@ -130,6 +130,7 @@ SIGNATURES = {
                                    C.c_void_p, i32, u64, u64, C.c_void_p, i32, P(C.c_void_p)]),
     "isl_hnsw_free": (None, [C.c_void_p]),
     "isl_hnsw_len": (u64, [C.c_void_p]),
+    "isl_hnsw_last_stats": (i32, [C.c_void_p, P(SearchStatsC)]),
     "isl_hnsw_search_batch": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
     "isl_pq_new": (i32, [u64, u64, u64, C.c_void_p, i32, i32, P(C.c_void_p)]),

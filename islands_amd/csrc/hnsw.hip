@@ -37,6 +37,11 @@ void isl_hnsw_free(isl_hnsw* h) {
 
 uint64_t isl_hnsw_len(const isl_hnsw* h) { return h && h->core ? h->core->num_nodes : 0; }
 
+isl_status isl_hnsw_last_stats(const isl_hnsw* h, isl_search_stats* out) {
+  if (!h || !h->core) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "hnsw handle is NULL");
+  return isl_search_last_stats(h->core, out);
+}
+
 isl_status isl_hnsw_from_layers(uint64_t m, uint64_t m0, uint64_t ef_construction, int32_t metric,
                                 uint64_t num_nodes, uint64_t d, uint64_t num_layers,
                                 const uint64_t* const* layer_offsets,

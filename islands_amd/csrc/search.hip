@@ -98,6 +98,7 @@ struct SearchParams {
   const uint64_t* const* layer_off;  // [max_level + 1] device pointers (index 0 unused)
   const uint32_t* const* layer_adj;
   uint32_t max_level;
+  uint32_t hnsw_order;  // fast kernel: heaps ordered on the distance alone, equal distances -> exact kernel
 };
 
 // ------------------------------------------------------------- sorted result set
@@ -200,14 +201,16 @@ struct RSet {
 // distances, more than kBatchMax candidates) returns false and takes the one-by-one loop.
 // The per-candidate loop has no serial SALU<->VALU round trip: its iterations only accumulate.
 constexpr uint32_t kBatchMax = 32;
+constexpr int BI_DONE = 1, BI_FALLBACK = 0, BI_TIE = 2;
 
 template <int S>
-__device__ __forceinline__ bool batch_insert(RSet<S>& rs, uint32_t ef, uint32_t wk0, uint64_t C,
-                                             uint32_t nk, uint32_t uid, uint32_t* mbuf) {
+__device__ __forceinline__ int batch_insert(RSet<S>& rs, uint32_t ef, uint32_t wk0, uint64_t C,
+                                            uint32_t nk, uint32_t uid, uint32_t* mbuf, bool strict_ties) {
   const uint32_t lane = threadIdx.x;
   const bool full = rs.len >= ef;
   const uint32_t nC = (uint32_t)__popcll(C);
-  if (nC > kBatchMax || (!full && rs.len + nC > ef)) return false;
+  const bool oversize = nC > kBatchMax || (!full && rs.len + nC > ef);
+  if (oversize && !strict_ties) return BI_FALLBACK;
   const bool inC = (C >> lane) & 1ull;
   uint32_t c[S], idm[S];
 #pragma unroll
@@ -234,9 +237,13 @@ __device__ __forceinline__ bool batch_insert(RSet<S>& rs, uint32_t ef, uint32_t 
     a = (int)lane == j ? aj : a;
   }
   (void)wk0;
+  // HnswGraph orders its heaps on the distance alone (hnsw.rs:136-141): with two equal distances
+  // in play the pop / eviction order is the heap's, not (distance, id) -> the exact kernel decides
+  if (strict_ties && ballot(tie)) return BI_TIE;
+  if (oversize) return BI_FALLBACK;
   if (full) {
-    if (ballot(inC && a + b >= ef)) return false;  // someone is no longer below the worst at its turn
-    if (ballot(tie)) return false;
+    if (ballot(inC && a + b >= ef)) return BI_FALLBACK;  // no longer below the worst at its turn
+    if (ballot(tie)) return BI_FALLBACK;
     // R's own largest nC + 1 distances must differ pairwise
     bool rt = false;
 #pragma unroll
@@ -246,7 +253,7 @@ __device__ __forceinline__ bool batch_insert(RSet<S>& rs, uint32_t ef, uint32_t 
       const uint32_t e = (uint32_t)s * 64u + lane;
       rt |= e >= ef - nC && e < ef && e > 0 && rs.kd[s] == prev;
     }
-    if (ballot(rt)) return false;
+    if (ballot(rt)) return BI_FALLBACK;
   }
   const uint32_t newlen = rs.len + nC < ef ? rs.len + nC : ef;
   uint32_t* mk = mbuf;
@@ -269,7 +276,7 @@ __device__ __forceinline__ bool batch_insert(RSet<S>& rs, uint32_t ef, uint32_t 
   }
   __syncthreads();
   rs.len = newlen;
-  return true;
+  return BI_DONE;
 }
 
 // Rust BinaryHeap ([external]: std): max-heap w.r.t. `less_eq`.  Operated by lane 0 only.
@@ -465,16 +472,51 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
     } else if (!rows_present(p, p.entry, 1)) {
       status = QS_BLOCKED;
     } else {
-      float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[p.entry] : 0.0f;
-      float ed = direct_distances<METRIC>(p.emb, p.stride, p.d, p.entry, 1, qs, q_norm, e_aux);
+      uint32_t entry = p.entry;
+      float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[entry] : 0.0f;
+      float ed = direct_distances<METRIC>(p.emb, p.stride, p.d, entry, 1, qs, q_norm, e_aux);
       ed = rl_f(ed, 0);
       cV = 1;
-      if (lane == 0) htab[hslot(p.entry, p.hbits)] = p.entry;
+      // HnswGraph::search, hnsw.rs:478-497: greedy descent from the top layer to layer 1 -- per
+      // round the neighbours of the node the round started at are scanned in order and `current`
+      // moves to every strictly closer one
+      for (uint32_t layer = p.max_level; layer >= 1 && status == QS_OK; --layer) {
+        const uint64_t* loff = p.layer_off[layer];
+        const uint32_t* ladj = p.layer_adj[layer];
+        for (;;) {
+          const uint64_t g0 = loff[entry], g1 = loff[entry + 1];
+          const uint32_t gdeg = (uint32_t)(g1 - g0);
+          bool changed = false;
+          uint32_t cur = entry;
+          float cur_d = ed;
+          for (uint32_t base = 0; base < gdeg && status == QS_OK; base += 64) {
+            const uint32_t R = gdeg - base < 64 ? gdeg - base : 64;
+            const uint32_t gid = (uint32_t)lane < R ? ladj[g0 + base + lane] : 0u;
+            const uint64_t gbad = ballot((uint32_t)lane < R && (uint64_t)gid >= p.nvec);
+            if (gbad) {  // HnswGraph::distance -> NodeNotFound, hnsw.rs:449-455
+              status = QS_NODE_NOT_FOUND;
+              payload = rl_u(gid, __ffsll((long long)gbad) - 1);
+              break;
+            }
+            const float g_aux = (METRIC == METRIC_COSINE_PRE && (uint32_t)lane < R) ? p.norm2[gid] : 0.0f;
+            const float gd = direct_distances<METRIC>(p.emb, p.stride, p.d, gid, R, qs, q_norm, g_aux);
+            cV += R;
+            for (uint32_t r = 0; r < R; ++r) {  // list order, strict `<` (hnsw.rs:485)
+              const float dr = rl_f(gd, (int)r);
+              if (dr < cur_d) { cur = rl_u(gid, (int)r); cur_d = dr; changed = true; }
+            }
+          }
+          entry = cur;
+          ed = cur_d;
+          if (!changed || status != QS_OK) break;
+        }
+      }
+      if (lane == 0) htab[hslot(entry, p.hbits)] = entry;
       hcount = 1;
-      if (odd_distance(ed)) { status = QS_REDO; payload = 5; }
-      rs.insert(ordkey(ed), p.entry, ef);
+      if (odd_distance(ed) && status == QS_OK) { status = QS_REDO; payload = 5; }
+      rs.insert(ordkey(ed), entry, ef);
       rs.len = 1;
-      if (lane == 0) plog[0] = make_uint2(__float_as_uint(ed), p.entry);
+      if (lane == 0) plog[0] = make_uint2(__float_as_uint(ed), entry);
       cP = 1;
       __syncthreads();
     }
@@ -593,7 +635,9 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
         const uint32_t wk0 = full0 ? rs.key_at(ef - 1) : KEY_MAX;
         const uint64_t C = ballot(nk < wk0) & pending;
         if (!C) { ISL_MARK(tp3) continue; }
-        if (batch_insert<S>(rs, ef, wk0, C, nk, uid, mbuf)) {
+        const int bi = batch_insert<S>(rs, ef, wk0, C, nk, uid, mbuf, p.hnsw_order != 0);
+        if (bi == BI_TIE) { status = QS_REDO; payload = 6; break; }
+        if (bi == BI_DONE) {
           const uint32_t rank = (uint32_t)__popcll(C & ((1ull << lane) - 1ull));
           if (((C >> lane) & 1ull) && cP + rank < p.plog_cap)
             plog[cP + rank] = make_uint2(__float_as_uint(nd), uid);
@@ -704,7 +748,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
         p.redo[atomicAdd(&p.ticket[1], 1u)] = qi;
         // why: 1 long row, 2 visited overflow, 3 tie-candidate overflow, 0 push-log overflow,
         // 5 a distance without an integer image (NaN, -0.0)
-        atomicAdd(&p.ticket[payload == 5 ? 12u : 8u + ((uint32_t)payload & 3u)], 1u);
+        atomicAdd(&p.ticket[payload == 5 ? 12u : payload == 6 ? 14u : 8u + ((uint32_t)payload & 3u)], 1u);
       }
     }
     if (ovf) {  // leave the overflow table empty for the next query of this slot
@@ -1156,7 +1200,7 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   if (hipGetDeviceProperties(&prop, idx->device) == hipSuccess) ncu = prop.multiProcessorCount;
 
   FastGeom fg = fast_geometry(ef, (uint32_t)d);
-  bool use_fast = ef <= 512 && ef >= 1 && idx->max_degree <= 64 && !idx->is_hnsw;
+  bool use_fast = ef <= 512 && ef >= 1 && idx->max_degree <= 64;
   // resident waves per CU: bounded by LDS (visited table + query) and by the kernel's VGPR
   // budget (<= 128 -> 4 per SIMD)
   size_t cu_cap = 16;
@@ -1240,6 +1284,7 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   p.layer_off = idx->d_layer_off;
   p.layer_adj = idx->d_layer_adj;
   p.max_level = idx->is_hnsw ? (uint32_t)idx->max_level : 0u;
+  p.hnsw_order = idx->is_hnsw ? 1u : 0u;
 
   ISL_HIP(hipMemsetAsync(ws.ticket, 0, 64, st));
   ISL_HIP(hipEventRecord(ws.ev0, st));

@@ -52,6 +52,9 @@ def test_hnsw_search_matches_oracle(orc, metric):
     assert_same(h, g, q, 10, 50)
     assert_same(h, g, v[:16], 5, 5)
     assert_same(h, g, q[:8], 20, 10)   # ef < k -> ef = k, hnsw.rs:500
+    g.search_batch(q, 10, 50)
+    st = g.last_stats()
+    assert st["queries"] == 40 and st["exact_path"] == 0  # one wave per query, no tie met
 
 
 def test_hnsw_d768_and_small_ef(orc):
@@ -68,6 +71,7 @@ def test_hnsw_ties_and_duplicates(orc):
     _, h, g = build(orc, v.shape[0], 8, 21, m=6, m0=12, ef_construction=30, vectors=v,
                     metric=ia.DistanceMetric.Euclidean)
     assert_same(h, g, base[:20], 10, 40)
+    assert g.last_stats()["exact_path"] > 0  # equal distances: the heap-exact kernel decides
 
 
 def test_hnsw_reference_shapes(orc):  # hnsw.rs:615-687
