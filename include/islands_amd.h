@@ -177,7 +177,11 @@ isl_status isl_index_upload(isl_index* idx, int32_t device);
 /* InMemoryEmbeddingProvider::new, leann.rs:111-120: attach n rows of d
  * elements as the provider for this index.  `rows` is row-major, on the host
  * or already on the index's device (mem = ISL_MEM_*).  The handle keeps its
- * own HBM copy (rows padded to 16-byte multiples).  n == 0 -> EmptyCollection. */
+ * own HBM copy (rows padded to 16-byte multiples).  n == 0 -> EmptyCollection.
+ * dtype ISL_DTYPE_BF16: `rows` holds bf16 bit patterns (u16) and is stored as such -- half the
+ * HBM bytes per visited node; the provider's vectors are their exact f32 images and the
+ * arithmetic stays the reference's f32 chain, so results equal the reference's on those f32
+ * rows.  (The HnswGraph facade, the builder and the distance / PQ entry points take f32.) */
 isl_status isl_set_embeddings(isl_index* idx, const void* rows, uint64_t n, uint64_t d,
                               int32_t dtype, int32_t mem);
 

@@ -431,6 +431,19 @@ class LeannIndex:
                                                  MEM_HOST))
         return self
 
+    def set_embeddings_bf16(self, rows_bits, device_ptr: int | None = None, n: int | None = None,
+                            d: int | None = None) -> "LeannIndex":
+        """In-memory provider with bf16 storage: `rows_bits` [n, d] uint16 bit patterns (or a
+        device pointer to them).  The provider's vectors are their exact f32 images."""
+        if device_ptr is not None:
+            _check(_ffi.lib().isl_set_embeddings(self._h, C.c_void_p(device_ptr), n, d, 1, MEM_DEVICE))
+        else:
+            r = np.ascontiguousarray(rows_bits, dtype=np.uint16)
+            if r.ndim != 2 or r.shape[0] == 0:
+                raise CoreError(2, "Empty vector collection")
+            _check(_ffi.lib().isl_set_embeddings(self._h, _ptr(r), r.shape[0], r.shape[1], 1, MEM_HOST))
+        return self
+
     def _attach(self, provider):
         if isinstance(provider, InMemoryEmbeddingProvider):
             key = id(provider.embeddings)

@@ -68,6 +68,7 @@ void free_workspace(SearchWorkspace& ws) {
   if (ws.h_ctr) (void)hipHostFree(ws.h_ctr);
   if (ws.h_head) (void)hipHostFree(ws.h_head);
   if (ws.d_prof) (void)hipFree(ws.d_prof);
+  if (ws.q_entry) (void)hipFree(ws.q_entry);
   if (ws.miss) (void)hipFree(ws.miss);
   if (ws.uniq) (void)hipFree(ws.uniq);
   if (ws.uniq_count) (void)hipFree(ws.uniq_count);
@@ -251,6 +252,7 @@ void isl_index_free(isl_index* idx) {
   if (!idx) return;
   if (idx->device >= 0) {
     (void)hipSetDevice(idx->device);
+    if (idx->d_emb16) (void)hipFree(idx->d_emb16);
     if (idx->d_tokens) (void)hipFree(idx->d_tokens);
     if (idx->d_lens) (void)hipFree(idx->d_lens);
     if (idx->d_present) (void)hipFree(idx->d_present);
@@ -445,6 +447,15 @@ __global__ void convert_adj_kernel(const uint64_t* __restrict__ in, uint32_t* __
     out[i] = (uint32_t)v;
   }
   if (bad) atomicOr(flags, 1u);
+}
+
+// bf16 bit patterns -> their exact f32 images
+__global__ void widen_bf16_kernel(const uint16_t* __restrict__ src, uint64_t sstride, uint32_t d, uint64_t n,
+                                  float* __restrict__ dst, uint64_t dstride) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * d) return;
+  const uint64_t r = i / d, c = i % d;
+  dst[r * dstride + c] = __uint_as_float((uint32_t)src[r * sstride + c] << 16);
 }
 
 // norm2[i] = sum_j rows[i][j]^2, sequential in j (one lane per row, rows staged through LDS).
@@ -659,15 +670,52 @@ isl_status isl_set_embeddings(isl_index* idx, const void* rows, uint64_t n, uint
                               int32_t dtype, int32_t mem) {
   if (!idx || (!rows && n)) return fail(ISL_ERR_INVALID_ARGUMENT, "NULL argument");
   if (n == 0) return fail(ISL_ERR_EMPTY_COLLECTION, "Empty vector collection");
-  if (dtype != ISL_DTYPE_F32)
-    return fail(ISL_ERR_UNSUPPORTED, "only f32 rows are supported by this build");
+  if (dtype != ISL_DTYPE_F32 && dtype != ISL_DTYPE_BF16)
+    return fail(ISL_ERR_INVALID_ARGUMENT, "unknown row dtype");
   if (d == 0 || d > 65536) return fail(ISL_ERR_INVALID_ARGUMENT, "dimension out of range");
   if (idx->device < 0)
     return fail(ISL_ERR_DEVICE, "call isl_index_upload before attaching embeddings");
   ISL_TRY(use_device(idx->device));
   std::lock_guard<std::mutex> lock(idx->mu);
   if (idx->d_emb) { (void)hipFree(idx->d_emb); idx->d_emb = nullptr; }
+  if (idx->d_emb16) { (void)hipFree(idx->d_emb16); idx->d_emb16 = nullptr; }
   idx->recompute = false;  // back to the in-memory provider
+  if (dtype == ISL_DTYPE_BF16) {
+    // rows are bf16 bit patterns; the provider's vectors are their exact f32 images.  Rows start
+    // 16-byte aligned (stride = d rounded up to 8 elements), 1 KiB of slack like the f32 table.
+    if (idx->is_hnsw) return fail(ISL_ERR_UNSUPPORTED, "the HnswGraph facade keeps f32 vectors");
+    const uint64_t stride16 = (d + 7) / 8 * 8;
+    const size_t bytes16 = (size_t)(n * stride16 + 512) * 2;
+    ISL_HIP(hipMalloc(&idx->d_emb16, bytes16));
+    ISL_HIP(hipMemset(idx->d_emb16, 0, bytes16));
+    hipMemcpyKind kind16 = mem == ISL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    ISL_HIP(hipMemcpy2D(idx->d_emb16, stride16 * 2, rows, d * 2, d * 2, n, kind16));
+    idx->nvec = n;
+    idx->emb_d = d;
+    idx->emb_stride = stride16;
+    if (idx->d_norm2) { (void)hipFree(idx->d_norm2); idx->d_norm2 = nullptr; }
+    ISL_HIP(hipMalloc(&idx->d_norm2, (size_t)n * 4));
+    // norm_b in the reference's order: widen a chunk of rows to f32 and reuse the f32 kernel
+    using namespace isl_dev;
+    const uint64_t stride32 = (d + 3) / 4 * 4;
+    const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(n, (256ull << 20) / (stride32 * 4)));
+    float* tmp = nullptr;
+    ISL_HIP(hipMalloc(&tmp, (size_t)(chunk * stride32 + 256) * 4));
+    ISL_HIP(hipMemset(tmp, 0, (size_t)(chunk * stride32 + 256) * 4));
+    const size_t lds = (size_t)TILE_ROWS * TILE_LD * 4 + 64;
+    for (uint64_t o = 0; o < n; o += chunk) {
+      const uint64_t c = std::min(chunk, n - o);
+      hipLaunchKernelGGL(widen_bf16_kernel, dim3((uint32_t)((c * d + 255) / 256)), dim3(256), 0, 0,
+                         idx->d_emb16 + o * stride16, stride16, (uint32_t)d, c, tmp, stride32);
+      hipLaunchKernelGGL(row_norm2_kernel, dim3((uint32_t)std::min<uint64_t>((c + 63) / 64, 8192)), dim3(64), lds,
+                         0, tmp, c, (uint32_t)d, stride32, idx->d_norm2 + o);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(ISL_ERR_DEVICE, "bf16 row upload failed: %s", hipGetErrorString(e));
+    return ISL_OK;
+  }
   uint64_t stride = (d + 3) / 4 * 4;  // rows start 16-byte aligned
   size_t bytes = (size_t)(n * stride + 256) * sizeof(float);  // slack for whole-slab reads
   ISL_HIP(hipMalloc(&idx->d_emb, bytes));

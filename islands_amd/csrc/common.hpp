@@ -86,6 +86,8 @@ struct SearchWorkspace {
   uint32_t* h_head = nullptr;
   uint64_t h_cap = 0;
   uint64_t* d_prof = nullptr;    // ISL_DEBUG phase timers of the call in flight
+  uint32_t* q_entry = nullptr;   // HnswGraph: [2][nq] layer-0 entry and descent evaluations per query
+  uint64_t q_entry_cap = 0;
   // recompute provider: node ids whose rows a search round found absent, and their unique set
   uint32_t* miss = nullptr;
   uint32_t* uniq = nullptr;
@@ -121,6 +123,7 @@ struct isl_index {
   uint32_t max_degree = 0;
   // in-memory provider (leann.rs:104-159): nvec rows, `stride` floats apart
   float* d_emb = nullptr;
+  uint16_t* d_emb16 = nullptr;  // bf16 rows (ISL_DTYPE_BF16) instead of d_emb
   float* d_norm2 = nullptr;  // [nvec] sum of squares of every row, reference summation order
   uint64_t nvec = 0, emb_d = 0, emb_stride = 0;
 

@@ -424,20 +424,170 @@ __device__ __forceinline__ float direct_group(const float* __restrict__ emb, uin
 }
 #undef ISL_RING
 
-// Tile-free counterpart of wave_distances: lane j < R receives the distance of row rid(j).
+// bf16 rows (ISL_DTYPE_BF16): the same quad layout with 8 elements per 16-byte load, so a step
+// covers 32 elements (lane s of the quad owns elements 32i + 8s .. + 7).  Every bf16 value is
+// exactly representable in f32 and widened before use: the arithmetic is the f32 chain of the
+// reference run on the widened rows.
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+#define ISL_RING(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11)
 template <int METRIC>
-__device__ __forceinline__ float direct_distances(const float* __restrict__ emb, uint64_t stride,
+__device__ __forceinline__ float direct_group_bf16(const uint16_t* __restrict__ emb, uint64_t stride,
+                                                   uint32_t d, uint32_t rid, uint32_t g0, uint32_t Rg,
+                                                   const float* qs, float q_norm, float row_aux) {
+  const int lane = threadIdx.x;
+  const uint32_t r = (uint32_t)lane >> 2;
+  const uint32_t s8 = ((uint32_t)lane & 3u) * 8u;
+  const uint32_t row = (uint32_t)__shfl((int)rid, (int)((g0 + (r < Rg ? r : 0u)) & 63u));
+  float a0 = 0.0f, a1 = 0.0f;
+  if (r < Rg) {
+    const uint16_t* rp = emb + (uint64_t)row * stride + s8;
+    const float* qp = qs + s8;
+    const uint32_t nF = d >> 5;
+    const uint32_t nS = (d + 31u) >> 5;
+#define ISL_ADD(ss, c)                                                           \
+  a0 += quad_bcast<ss>(p##c);                                                     \
+  if constexpr (METRIC == ISL_METRIC_COSINE) a1 += quad_bcast<ss>(n##c);
+#define ISL_ADD_G(ss, c) if (e0 + 8 * (ss) + (c) < d) { ISL_ADD(ss, c) }
+#define ISL_OCT(A, ss) A(ss, 0) A(ss, 1) A(ss, 2) A(ss, 3) A(ss, 4) A(ss, 5) A(ss, 6) A(ss, 7)
+#define ISL_WIDEN                                                                               \
+  const float w0 = __uint_as_float(xv.x << 16), w1 = __uint_as_float(xv.x & 0xFFFF0000u),      \
+              w2 = __uint_as_float(xv.y << 16), w3 = __uint_as_float(xv.y & 0xFFFF0000u),      \
+              w4 = __uint_as_float(xv.z << 16), w5 = __uint_as_float(xv.z & 0xFFFF0000u),      \
+              w6 = __uint_as_float(xv.w << 16), w7 = __uint_as_float(xv.w & 0xFFFF0000u);
+#define ISL_TERMS                                                                               \
+  const float p0 = dterm<METRIC>(qa.x, w0), p1 = dterm<METRIC>(qa.y, w1),                      \
+              p2 = dterm<METRIC>(qa.z, w2), p3 = dterm<METRIC>(qa.w, w3),                      \
+              p4 = dterm<METRIC>(qb.x, w4), p5 = dterm<METRIC>(qb.y, w5),                      \
+              p6 = dterm<METRIC>(qb.z, w6), p7 = dterm<METRIC>(qb.w, w7);                      \
+  const float n0 = w0 * w0, n1 = w1 * w1, n2 = w2 * w2, n3 = w3 * w3, n4 = w4 * w4,            \
+              n5 = w5 * w5, n6 = w6 * w6, n7 = w7 * w7;                                        \
+  (void)n0; (void)n1; (void)n2; (void)n3; (void)n4; (void)n5; (void)n6; (void)n7;
+#define ISL_DECLX(k) v4u x##k;
+#define ISL_ISSUE(k) x##k = *reinterpret_cast<const v4u*>(rp + 32u * (base + (k)));
+#define ISL_PIN __builtin_amdgcn_sched_barrier(0x40F);
+#define ISL_TAKE(k)                                                               \
+    v4u xv = x##k;                                                                \
+    asm volatile("" : "+v"(xv));
+#define ISL_QNEXT(k)                                                              \
+    {                                                                             \
+      const uint32_t sn_ = base + (k) + 1u < nS ? base + (k) + 1u : nS - 1u;      \
+      qna = *reinterpret_cast<const float4*>(qp + 32u * sn_);                     \
+      qnb = *reinterpret_cast<const float4*>(qp + 32u * sn_ + 4u);                \
+    }
+#define ISL_ALL_ADDS ISL_OCT(ISL_ADD, 0) ISL_OCT(ISL_ADD, 1) ISL_OCT(ISL_ADD, 2) ISL_OCT(ISL_ADD, 3)
+#define ISL_STEP_RELOAD(k)                                                        \
+  {                                                                               \
+    ISL_TAKE(k)                                                                   \
+    const float4 qa = qna, qb = qnb;                                              \
+    ISL_WIDEN                                                                     \
+    ISL_TERMS                                                                     \
+    ISL_PIN                                                                       \
+    x##k = *reinterpret_cast<const v4u*>(rp + 32u * (base + RING + (k)));         \
+    ISL_QNEXT(k)                                                                  \
+    ISL_PIN                                                                       \
+    ISL_ALL_ADDS                                                                  \
+  }
+#define ISL_STEP(k)                                                               \
+  {                                                                               \
+    ISL_TAKE(k)                                                                   \
+    const float4 qa = qna, qb = qnb;                                              \
+    ISL_WIDEN                                                                     \
+    ISL_TERMS                                                                     \
+    ISL_PIN                                                                       \
+    ISL_QNEXT(k)                                                                  \
+    ISL_PIN                                                                       \
+    ISL_ALL_ADDS                                                                  \
+  }
+    ISL_RING(ISL_DECLX)
+    uint32_t base = 0;
+    if (nF >= (uint32_t)RING) {
+      ISL_RING(ISL_ISSUE)
+      float4 qna = *reinterpret_cast<const float4*>(qp), qnb = *reinterpret_cast<const float4*>(qp + 4);
+      ISL_PIN
+      while (base + 2u * RING <= nF) {
+        ISL_RING(ISL_STEP_RELOAD)
+        base += RING;
+      }
+      ISL_RING(ISL_STEP)
+      base += RING;
+    }
+    if (base < nS) {
+      const uint32_t rem = nS - base;
+      const uint32_t last = nS - 1u;
+#define ISL_ISSUE_C(k)                                                              \
+  {                                                                                 \
+    const uint32_t st_ = base + (k) < last ? base + (k) : last;                     \
+    x##k = *reinterpret_cast<const v4u*>(rp + 32u * st_);                           \
+  }
+#define ISL_STEP_G(k)                                                               \
+  if ((uint32_t)(k) < rem) {                                                        \
+    const uint32_t e0 = 32u * (base + (k));                                         \
+    ISL_TAKE(k)                                                                     \
+    float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;                           \
+    const uint32_t dq_ = (d + 3u) & ~3u;                                            \
+    if (e0 + s8 < dq_) qa = *reinterpret_cast<const float4*>(qp + e0);              \
+    if (e0 + s8 + 4u < dq_) qb = *reinterpret_cast<const float4*>(qp + e0 + 4u);    \
+    ISL_WIDEN                                                                       \
+    ISL_TERMS                                                                       \
+    ISL_OCT(ISL_ADD_G, 0) ISL_OCT(ISL_ADD_G, 1) ISL_OCT(ISL_ADD_G, 2) ISL_OCT(ISL_ADD_G, 3) \
+  }
+      ISL_RING(ISL_ISSUE_C)
+      ISL_RING(ISL_STEP_G)
+#undef ISL_ISSUE_C
+#undef ISL_STEP_G
+    }
+#undef ISL_ADD
+#undef ISL_ADD_G
+#undef ISL_OCT
+#undef ISL_WIDEN
+#undef ISL_TERMS
+#undef ISL_DECLX
+#undef ISL_ISSUE
+#undef ISL_PIN
+#undef ISL_TAKE
+#undef ISL_QNEXT
+#undef ISL_ALL_ADDS
+#undef ISL_STEP_RELOAD
+#undef ISL_STEP
+  }
+  if (METRIC == METRIC_COSINE_PRE) a1 = __shfl(row_aux, (int)((g0 + r) & 63u));
+  return dfinish<METRIC>(a0, a1, q_norm);
+}
+#undef ISL_RING
+
+// Tile-free counterpart of wave_distances: lane j < R receives the distance of row rid(j).
+// ROWT = float or uint16_t (bf16 bits).
+template <int METRIC, typename ROWT = float>
+__device__ __forceinline__ float direct_distances(const ROWT* __restrict__ emb, uint64_t stride,
                                                   uint32_t d, uint32_t rid, uint32_t R,
                                                   const float* qs, float q_norm, float row_aux = 0.0f) {
   const int lane = threadIdx.x;
   float result = 0.0f;
   for (uint32_t g0 = 0; g0 < R; g0 += GROUP) {
     const uint32_t Rg = R - g0 < (uint32_t)GROUP ? R - g0 : (uint32_t)GROUP;
-    float dist = direct_group<METRIC>(emb, stride, d, rid, g0, Rg, qs, q_norm, row_aux);
+    float dist;
+    if constexpr (sizeof(ROWT) == 2)
+      dist = direct_group_bf16<METRIC>(reinterpret_cast<const uint16_t*>(emb), stride, d, rid, g0, Rg, qs, q_norm, row_aux);
+    else
+      dist = direct_group<METRIC>(reinterpret_cast<const float*>(emb), stride, d, rid, g0, Rg, qs, q_norm, row_aux);
     float moved = __shfl(dist, (4 * (lane - (int)g0)) & 63);
     if ((uint32_t)lane >= g0 && (uint32_t)lane < g0 + Rg) result = moved;
   }
   return result;
+}
+
+// Slow generic form for bf16 rows in the heap-exact kernel: lane j < R walks its own row.
+template <int METRIC>
+__device__ __forceinline__ float lane_distances_bf16(const uint16_t* __restrict__ emb, uint64_t stride,
+                                                     uint32_t d, uint32_t rid, uint32_t R,
+                                                     const float* qs, float q_norm, float row_aux) {
+  float a0 = 0.0f, a1 = 0.0f;
+  if ((uint32_t)threadIdx.x < R) {
+    const uint16_t* rp = emb + (uint64_t)rid * stride;
+    for (uint32_t j = 0; j < d; ++j) dstep<METRIC>(qs[j], __uint_as_float((uint32_t)rp[j] << 16), a0, a1);
+  }
+  if (METRIC == METRIC_COSINE_PRE) a1 = row_aux;
+  return dfinish<METRIC>(a0, a1, q_norm);
 }
 
 // Copies the query at `q` (global) into LDS and returns norm_a of cosine_distance

@@ -51,7 +51,8 @@ struct SearchParams {
   const uint64_t* off;
   const uint32_t* adj;
   uint64_t num_nodes;
-  const float* emb;
+  const void* emb;     // rows: f32, or bf16 bits when emb_bf16
+  uint32_t emb_bf16;
   const float* norm2;  // per-row sum of squares (cosine only), reference order
   uint64_t nvec;
   uint64_t stride;  // floats between rows
@@ -99,6 +100,8 @@ struct SearchParams {
   const uint32_t* const* layer_adj;
   uint32_t max_level;
   uint32_t hnsw_order;  // fast kernel: heaps ordered on the distance alone, equal distances -> exact kernel
+  uint32_t* q_entry;    // [nq] layer-0 entry per query after the greedy descent (HnswGraph), or NULL
+  uint32_t* q_evals;    // [nq] distance evaluations of the descent (+ 1 for the entry point)
 };
 
 // ------------------------------------------------------------- sorted result set
@@ -403,6 +406,71 @@ __device__ void replay_result_order(const uint2* plog, uint32_t npush, uint32_t 
   __syncthreads();
 }
 
+// HnswGraph::search, hnsw.rs:478-497: greedy descent from the top layer to layer 1 -- per round
+// the neighbours of the node the round started at are scanned in order and `current` moves to
+// every strictly closer one.  One wave per query; leaves the layer-0 entry in q_entry (a missing
+// node id is reported through status / payload like everywhere else).
+template <int METRIC_API>
+__global__ __launch_bounds__(64) void hnsw_descent_kernel(SearchParams p) {
+  constexpr int METRIC = METRIC_API == ISL_METRIC_COSINE ? METRIC_COSINE_PRE : METRIC_API;
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* qs = reinterpret_cast<float*>(smem);
+  const float* emb = reinterpret_cast<const float*>(p.emb);
+  const int lane = threadIdx.x;
+  for (uint32_t qi = blockIdx.x; qi < p.nq; qi += gridDim.x) {
+    __syncthreads();
+    const float q_norm = load_query<METRIC>(p.queries + (uint64_t)qi * p.d, p.d, qs);
+    uint32_t status = QS_OK, cV = 1;
+    uint64_t payload = 0;
+    uint32_t entry = p.entry;
+    float ed = 0.0f;
+    if ((uint64_t)entry >= p.nvec) {
+      status = QS_NODE_NOT_FOUND;
+      payload = entry;
+    } else {
+      float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[entry] : 0.0f;
+      ed = rl_f(direct_distances<METRIC>(emb, p.stride, p.d, entry, 1, qs, q_norm, e_aux), 0);
+      for (uint32_t layer = p.max_level; layer >= 1 && status == QS_OK; --layer) {
+        const uint64_t* loff = p.layer_off[layer];
+        const uint32_t* ladj = p.layer_adj[layer];
+        for (;;) {
+          const uint64_t g0 = loff[entry], g1 = loff[entry + 1];
+          const uint32_t gdeg = (uint32_t)(g1 - g0);
+          bool changed = false;
+          uint32_t cur = entry;
+          float cur_d = ed;
+          for (uint32_t base = 0; base < gdeg && status == QS_OK; base += 64) {
+            const uint32_t R = gdeg - base < 64 ? gdeg - base : 64;
+            const uint32_t gid = (uint32_t)lane < R ? ladj[g0 + base + lane] : 0u;
+            const uint64_t gbad = ballot((uint32_t)lane < R && (uint64_t)gid >= p.nvec);
+            if (gbad) {  // HnswGraph::distance -> NodeNotFound, hnsw.rs:449-455
+              status = QS_NODE_NOT_FOUND;
+              payload = rl_u(gid, __ffsll((long long)gbad) - 1);
+              break;
+            }
+            const float g_aux = (METRIC == METRIC_COSINE_PRE && (uint32_t)lane < R) ? p.norm2[gid] : 0.0f;
+            const float gd = direct_distances<METRIC>(emb, p.stride, p.d, gid, R, qs, q_norm, g_aux);
+            cV += R;
+            for (uint32_t r = 0; r < R; ++r) {  // list order, strict `<` (hnsw.rs:485)
+              const float dr = rl_f(gd, (int)r);
+              if (dr < cur_d) { cur = rl_u(gid, (int)r); cur_d = dr; changed = true; }
+            }
+          }
+          entry = cur;
+          ed = cur_d;
+          if (!changed || status != QS_OK) break;
+        }
+      }
+    }
+    if (lane == 0) {
+      p.q_entry[qi] = entry;
+      p.q_evals[qi] = cV;
+      p.status[qi] = status;
+      p.payload[qi] = payload;
+    }
+  }
+}
+
 // Recompute provider: true when every row of `uid` (lanes < n) is materialised; otherwise the
 // absent ids are appended to the miss list and the caller stops the query with QS_BLOCKED.
 __device__ __forceinline__ bool rows_present(const SearchParams& p, uint32_t uid, uint32_t n) {
@@ -420,9 +488,10 @@ __device__ __forceinline__ bool rows_present(const SearchParams& p, uint32_t uid
 }
 
 // ------------------------------------------------------------------ fast kernel
-template <int S, int METRIC_API>
+template <int S, int METRIC_API, typename ROWT>
 __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
   constexpr int METRIC = METRIC_API == ISL_METRIC_COSINE ? METRIC_COSINE_PRE : METRIC_API;
+  const ROWT* const emb = reinterpret_cast<const ROWT*>(p.emb);
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
   const uint32_t hcap = 1u << p.hbits;
@@ -445,6 +514,13 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
     qi = uni(qi);
     if (qi >= p.nq) break;
 
+    if (p.q_entry && p.status[qi] != QS_OK) {  // the greedy descent already failed this query
+      if (lane == 0) {
+        p.out_count[qi] = 0;
+        p.ctr[qi * 4 + 0] = 0; p.ctr[qi * 4 + 1] = 0; p.ctr[qi * 4 + 2] = p.q_evals[qi]; p.ctr[qi * 4 + 3] = 0;
+      }
+      continue;
+    }
     const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
     for (uint32_t i = lane; i < hcap; i += 64) htab[i] = EMPTY;
     const float q_norm = load_query<METRIC>(p.queries + (uint64_t)qi * p.d, p.d, qs);  // syncs
@@ -466,51 +542,18 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
 #define ISL_MARK(acc) if (p.prof) { uint64_t now_ = __builtin_amdgcn_s_memrealtime(); acc += now_ - tmark; tmark = now_; }
 
     // entry point: provider.compute_embedding(entry) + distance, leann.rs:911-916
-    if ((uint64_t)p.entry >= p.nvec) {
+    if (!p.q_entry && (uint64_t)p.entry >= p.nvec) {
       status = QS_NODE_NOT_FOUND;
       payload = p.entry;
     } else if (!rows_present(p, p.entry, 1)) {
       status = QS_BLOCKED;
     } else {
-      uint32_t entry = p.entry;
+      // HnswGraph: the layer-0 search starts where the greedy descent (hnsw_descent_kernel) ended
+      const uint32_t entry = p.q_entry ? p.q_entry[qi] : p.entry;
       float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[entry] : 0.0f;
-      float ed = direct_distances<METRIC>(p.emb, p.stride, p.d, entry, 1, qs, q_norm, e_aux);
+      float ed = direct_distances<METRIC, ROWT>(emb, p.stride, p.d, entry, 1, qs, q_norm, e_aux);
       ed = rl_f(ed, 0);
-      cV = 1;
-      // HnswGraph::search, hnsw.rs:478-497: greedy descent from the top layer to layer 1 -- per
-      // round the neighbours of the node the round started at are scanned in order and `current`
-      // moves to every strictly closer one
-      for (uint32_t layer = p.max_level; layer >= 1 && status == QS_OK; --layer) {
-        const uint64_t* loff = p.layer_off[layer];
-        const uint32_t* ladj = p.layer_adj[layer];
-        for (;;) {
-          const uint64_t g0 = loff[entry], g1 = loff[entry + 1];
-          const uint32_t gdeg = (uint32_t)(g1 - g0);
-          bool changed = false;
-          uint32_t cur = entry;
-          float cur_d = ed;
-          for (uint32_t base = 0; base < gdeg && status == QS_OK; base += 64) {
-            const uint32_t R = gdeg - base < 64 ? gdeg - base : 64;
-            const uint32_t gid = (uint32_t)lane < R ? ladj[g0 + base + lane] : 0u;
-            const uint64_t gbad = ballot((uint32_t)lane < R && (uint64_t)gid >= p.nvec);
-            if (gbad) {  // HnswGraph::distance -> NodeNotFound, hnsw.rs:449-455
-              status = QS_NODE_NOT_FOUND;
-              payload = rl_u(gid, __ffsll((long long)gbad) - 1);
-              break;
-            }
-            const float g_aux = (METRIC == METRIC_COSINE_PRE && (uint32_t)lane < R) ? p.norm2[gid] : 0.0f;
-            const float gd = direct_distances<METRIC>(p.emb, p.stride, p.d, gid, R, qs, q_norm, g_aux);
-            cV += R;
-            for (uint32_t r = 0; r < R; ++r) {  // list order, strict `<` (hnsw.rs:485)
-              const float dr = rl_f(gd, (int)r);
-              if (dr < cur_d) { cur = rl_u(gid, (int)r); cur_d = dr; changed = true; }
-            }
-          }
-          entry = cur;
-          ed = cur_d;
-          if (!changed || status != QS_OK) break;
-        }
-      }
+      cV = p.q_entry ? p.q_evals[qi] : 1;
       if (lane == 0) htab[hslot(entry, p.hbits)] = entry;
       hcount = 1;
       if (odd_distance(ed) && status == QS_OK) { status = QS_REDO; payload = 5; }
@@ -622,7 +665,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       nhops_rows += 1;
       ISL_MARK(tp1)  // visited set + compaction
       float r_aux = (METRIC == METRIC_COSINE_PRE && (uint32_t)lane < keep) ? p.norm2[uid] : 0.0f;
-      float nd = direct_distances<METRIC>(p.emb, p.stride, p.d, uid, keep, qs, q_norm, r_aux);
+      float nd = direct_distances<METRIC, ROWT>(emb, p.stride, p.d, uid, keep, qs, q_norm, r_aux);
       ISL_MARK(tp2)  // row fetch + distances
 
       // leann.rs:953-970 in CSR order; worst = results.peek().  NaN / -0.0 distances have no
@@ -758,9 +801,16 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
   }
 }
 
-}  // namespace
-#include "search_quad.cuh"
-namespace {
+
+// rows of the exact kernel: the LDS-tile routine for f32 rows, a plain per-lane walk for bf16
+template <int METRIC>
+__device__ __forceinline__ float exact_rows(const SearchParams& p, uint32_t rid, uint32_t R,
+                                            const float* qs, float* tile, float q_norm, float aux) {
+  if (p.emb_bf16)
+    return lane_distances_bf16<METRIC>(reinterpret_cast<const uint16_t*>(p.emb), p.stride, p.d, rid, R, qs,
+                                       q_norm, aux);
+  return wave_distances<METRIC>(reinterpret_cast<const float*>(p.emb), p.stride, p.d, rid, R, qs, tile, q_norm, aux);
+}
 
 // ----------------------------------------------------------------- exact kernel
 // HNSW = true: HnswGraph::search (hnsw.rs:458-504): greedy descent through the upper layers,
@@ -812,7 +862,7 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
     } else {
       uint32_t entry = p.entry;
       float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[entry] : 0.0f;
-      float ed = rl_f(wave_distances<METRIC>(p.emb, p.stride, p.d, entry, 1, qs, tile, q_norm, e_aux), 0);
+      float ed = rl_f(exact_rows<METRIC>(p, entry, 1, qs, tile, q_norm, e_aux), 0);
       cV = 1;
       if (HNSW) {
         // greedy search from the top layer down to layer 1, hnsw.rs:478-497: per round the
@@ -837,7 +887,7 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
                 break;
               }
               float r_aux = (METRIC == METRIC_COSINE_PRE && (uint32_t)lane < R) ? p.norm2[nid] : 0.0f;
-              float nd = wave_distances<METRIC>(p.emb, p.stride, p.d, nid, R, qs, tile, q_norm, r_aux);
+              float nd = exact_rows<METRIC>(p, nid, R, qs, tile, q_norm, r_aux);
               cV += R;
               for (uint32_t r = 0; r < R; ++r) {  // in list order, strict `<` (hnsw.rs:485)
                 float dr = rl_f(nd, (int)r);
@@ -940,7 +990,7 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
         uint32_t R = keep - base < 64 ? keep - base : 64;
         uint32_t uid = (uint32_t)lane < R ? ulist[base + lane] : 0u;
         float r_aux = (METRIC == METRIC_COSINE_PRE && (uint32_t)lane < R) ? p.norm2[uid] : 0.0f;
-        float nd = wave_distances<METRIC>(p.emb, p.stride, p.d, uid, R, qs, tile, q_norm, r_aux);
+        float nd = exact_rows<METRIC>(p, uid, R, qs, tile, q_norm, r_aux);
         if ((uint32_t)lane < R) {
           dscratch[lane] = nd;
           scratch[lane] = uid;
@@ -1041,24 +1091,19 @@ void launch_one(K kernel, uint32_t grid, size_t lds, hipStream_t st, const Searc
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, st, p);
 }
 
-template <int S>
-void launch_fast(int metric, uint32_t grid, size_t lds, hipStream_t st, const SearchParams& p) {
+template <int S, typename ROWT>
+void launch_fast_t(int metric, uint32_t grid, size_t lds, hipStream_t st, const SearchParams& p) {
   switch (metric) {
-    case ISL_METRIC_COSINE: launch_one(leann_search_fast<S, ISL_METRIC_COSINE>, grid, lds, st, p); break;
-    case ISL_METRIC_EUCLIDEAN: launch_one(leann_search_fast<S, ISL_METRIC_EUCLIDEAN>, grid, lds, st, p); break;
-    case ISL_METRIC_DOT: launch_one(leann_search_fast<S, ISL_METRIC_DOT>, grid, lds, st, p); break;
-    default: launch_one(leann_search_fast<S, ISL_METRIC_MANHATTAN>, grid, lds, st, p); break;
+    case ISL_METRIC_COSINE: launch_one(leann_search_fast<S, ISL_METRIC_COSINE, ROWT>, grid, lds, st, p); break;
+    case ISL_METRIC_EUCLIDEAN: launch_one(leann_search_fast<S, ISL_METRIC_EUCLIDEAN, ROWT>, grid, lds, st, p); break;
+    case ISL_METRIC_DOT: launch_one(leann_search_fast<S, ISL_METRIC_DOT, ROWT>, grid, lds, st, p); break;
+    default: launch_one(leann_search_fast<S, ISL_METRIC_MANHATTAN, ROWT>, grid, lds, st, p); break;
   }
 }
-
-template <int NS>
-void launch_quad(int metric, uint32_t grid, size_t lds, hipStream_t st, const SearchParams& p) {
-  switch (metric) {
-    case ISL_METRIC_COSINE: launch_one(leann_search_quad<NS, ISL_METRIC_COSINE>, grid, lds, st, p); break;
-    case ISL_METRIC_EUCLIDEAN: launch_one(leann_search_quad<NS, ISL_METRIC_EUCLIDEAN>, grid, lds, st, p); break;
-    case ISL_METRIC_DOT: launch_one(leann_search_quad<NS, ISL_METRIC_DOT>, grid, lds, st, p); break;
-    default: launch_one(leann_search_quad<NS, ISL_METRIC_MANHATTAN>, grid, lds, st, p); break;
-  }
+template <int S>
+void launch_fast(int metric, uint32_t grid, size_t lds, hipStream_t st, const SearchParams& p) {
+  if (p.emb_bf16) launch_fast_t<S, uint16_t>(metric, grid, lds, st, p);
+  else launch_fast_t<S, float>(metric, grid, lds, st, p);
 }
 
 template <bool HNSW>
@@ -1208,24 +1253,9 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   uint32_t per_cu = (uint32_t)std::min<size_t>(cu_cap, (160 * 1024) / fg.lds);
   if (per_cu == 0) use_fast = false;
   uint32_t slots = std::max<uint32_t>(1, (uint32_t)ncu * std::max<uint32_t>(per_cu, 1));
-  // four queries per wave (search_quad.cuh) whenever the result set fits 8 slots x 16 lanes
-  uint32_t quad_hbits = ef <= 64 ? 10 : 11;
-  if (const char* hb = getenv("ISL_QUAD_HBITS")) quad_hbits = (uint32_t)atoi(hb);
-  const size_t quad_lds = ((size_t)16 << quad_hbits) + (size_t)QTILE_ROWS * QTILE_LD * 4 + 256 + 1024 +
-                          (size_t)4 * (((d + 3) / 4 * 4) + 16) * 4;
-  // Experimental (ISL_QUAD=1): correct (same parity tests) but 3.4x slower than the one-query
-  // kernel in round 1 -- only 2 waves per CU fit (four 8-KiB visited tables per wave) and a
-  // lockstep step costs 35 us; see DESIGN.md section 4.
-  bool use_quad = use_fast && ef <= 128 && quad_lds <= 160 * 1024 && getenv("ISL_QUAD");
-  uint32_t quad_per_cu = use_quad ? (uint32_t)std::min<size_t>(4, (160 * 1024) / quad_lds) : 0;
-  uint32_t quad_grid = 0;
-  if (use_quad) {
-    quad_grid = (uint32_t)std::min<uint64_t>((nq + 3) / 4, (uint64_t)ncu * quad_per_cu);
-    slots = std::max<uint32_t>(slots, quad_grid * 4);
-  }
   const uint32_t plog_cap = std::max<uint32_t>(1024, 12 * ef);  // pushes per query ~ 3-6 x ef
   // per-slot state is indexed by blockIdx.x < min(nq, slots)
-  ISL_TRY(prepare_workspace(ws, (uint32_t)nq, (uint32_t)std::min<uint64_t>(nq + 3, slots), plog_cap));
+  ISL_TRY(prepare_workspace(ws, (uint32_t)nq, (uint32_t)std::min<uint64_t>(nq, slots), plog_cap));
   ISL_TRY(prepare_exact(idx, ws));
   hipStream_t st = mode == StreamMode::USER ? user_stream : ws.stream;
   if (mode == StreamMode::OWN_AFTER_USER) {
@@ -1239,7 +1269,8 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   p.ell_w = idx->d_ell ? idx->ell_w : 0u;
   p.ell_deg = idx->d_ell_deg;
   p.num_nodes = idx->num_nodes;
-  p.emb = idx->d_emb;
+  p.emb = idx->d_emb16 ? (const void*)idx->d_emb16 : (const void*)idx->d_emb;
+  p.emb_bf16 = idx->d_emb16 ? 1u : 0u;
   p.norm2 = idx->d_norm2;
   p.nvec = idx->nvec;
   p.stride = idx->emb_stride;
@@ -1285,20 +1316,34 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   p.layer_adj = idx->d_layer_adj;
   p.max_level = idx->is_hnsw ? (uint32_t)idx->max_level : 0u;
   p.hnsw_order = idx->is_hnsw ? 1u : 0u;
+  p.q_entry = nullptr;
+  p.q_evals = nullptr;
 
   ISL_HIP(hipMemsetAsync(ws.ticket, 0, 64, st));
   ISL_HIP(hipEventRecord(ws.ev0, st));
-  if (use_quad) {
-    SearchParams pq = p;
-    pq.hbits = quad_hbits;
-    const int metric = (int)idx->cfg.metric;
-    if (ef <= 32) launch_quad<2>(metric, quad_grid, quad_lds, st, pq);
-    else launch_quad<8>(metric, quad_grid, quad_lds, st, pq);
+  if (use_fast && idx->is_hnsw && p.max_level > 0) {
+    // HnswGraph::search: greedy descent through the upper layers first (its own kernel, so that
+    // the traversal kernel keeps its register budget)
+    if (ws.q_entry_cap < nq) {
+      if (ws.q_entry) (void)hipFree(ws.q_entry);
+      ws.q_entry = nullptr;
+      ws.q_entry_cap = 0;
+      ISL_HIP(hipMalloc(&ws.q_entry, nq * 8));
+      ws.q_entry_cap = nq;
+    }
+    p.q_entry = ws.q_entry;
+    p.q_evals = ws.q_entry + nq;
+    const size_t dlds = (size_t)((d + 3) / 4 * 4) * 4 + 64;
+    const uint32_t dgrid = (uint32_t)std::min<uint64_t>(nq, 8192);
+    switch ((int)idx->cfg.metric) {
+      case ISL_METRIC_COSINE: launch_one(hnsw_descent_kernel<ISL_METRIC_COSINE>, dgrid, dlds, st, p); break;
+      case ISL_METRIC_EUCLIDEAN: launch_one(hnsw_descent_kernel<ISL_METRIC_EUCLIDEAN>, dgrid, dlds, st, p); break;
+      case ISL_METRIC_DOT: launch_one(hnsw_descent_kernel<ISL_METRIC_DOT>, dgrid, dlds, st, p); break;
+      default: launch_one(hnsw_descent_kernel<ISL_METRIC_MANHATTAN>, dgrid, dlds, st, p); break;
+    }
     ISL_HIP(hipGetLastError());
-    size_t rlds = (size_t)(ef + 1) * 8 + 16 + 64 * 8 + 16;
-    launch_one(leann_replay_order, 64, rlds, st, pq);
-    ISL_HIP(hipGetLastError());
-  } else if (use_fast) {
+  }
+  if (use_fast) {
     uint32_t grid = (uint32_t)std::min<uint64_t>(nq, slots);
     int S = ef <= 64 ? 1 : ef <= 128 ? 2 : ef <= 256 ? 4 : 8;
     const int metric = (int)idx->cfg.metric;
@@ -1530,7 +1575,7 @@ isl_status precheck(const isl_index* idx, uint64_t nq, uint64_t d, uint64_t k, u
   if (!idx->has_entry) return isl::fail(ISL_ERR_INDEX_NOT_BUILT, "Index not built");  // :889
   if (idx->device < 0 || !idx->d_off)
     return isl::fail(ISL_ERR_DEVICE, "index is not resident on a device (isl_index_upload)");
-  if (!idx->d_emb)
+  if (!idx->d_emb && !idx->d_emb16)
     return isl::fail(ISL_ERR_EMBEDDING, "Embedding error: no embedding provider attached");
   if (d != idx->emb_d)  // metric.calculate length check, distance.rs:39-44
     return isl::fail_dim(d, idx->emb_d);

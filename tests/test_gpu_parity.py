@@ -369,3 +369,52 @@ def test_bruteforce_topk(orc):
                 assert ids[i, j] == order[j]
     few = ia.bruteforce_topk(ia.DistanceMetric.DotProduct, q[:2], rows[:4], 10)
     assert few[2].tolist() == [4, 4]
+
+
+# ---------------------------------------------------------------- bf16 row storage
+def to_bf16_bits(a):
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def widen(bits):
+    return (bits.astype(np.uint32) << 16).view(np.float32)
+
+
+@pytest.mark.parametrize("metric", METRICS)
+@pytest.mark.parametrize("d", [40, 768])
+def test_bf16_rows_match_oracle_on_widened_rows(orc, metric, d):
+    """ISL_DTYPE_BF16: the provider's vectors are the exact f32 images of the stored bf16 values,
+    the arithmetic is the reference's f32 chain -> ids and distance bits of the oracle run on
+    the widened rows."""
+    n = 900
+    bits = to_bf16_bits(clustered_vectors(n, d, 31))
+    rows = widen(bits)
+    csr = orc.leann_build(rows, m=8, m0=16, ef_construction=40, metric=int(metric))
+    cfg = ia.LeannConfig(m=8, m0=16, ef_construction=40, metric=metric)
+    g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels,
+                    entry_point=csr.entry_point, max_level=csr.max_level, num_nodes=csr.num_nodes,
+                    degree_counts=csr.degree_counts)
+    idx = ia.LeannIndex.from_csr(g, cfg, dimension=d)
+    idx.upload(0)
+    idx.set_embeddings_bf16(bits)
+    q = clustered_vectors(24, d, 32)
+    st, tot = assert_same_search(orc, idx, csr, rows, q, 10, 48, metric=int(metric))
+    for f in tot:
+        assert st[f] == tot[f], f
+    assert st["exact_path"] == 0
+
+
+def test_bf16_rows_ties_take_the_exact_kernel(orc):
+    base = to_bf16_bits(uniform_vectors(80, 24, 3))
+    bits = np.concatenate([base, base, base[:40]])
+    rows = widen(bits)
+    csr = orc.leann_build(rows, m=6, m0=12, ef_construction=30)
+    g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels,
+                    entry_point=csr.entry_point, max_level=csr.max_level, num_nodes=csr.num_nodes,
+                    degree_counts=csr.degree_counts)
+    idx = ia.LeannIndex.from_csr(g, ia.LeannConfig(m=6, m0=12, ef_construction=30), dimension=24)
+    idx.upload(0)
+    idx.set_embeddings_bf16(bits)
+    st, _ = assert_same_search(orc, idx, csr, rows, rows[:16], 10, 30)
+    assert st["exact_path"] + st["replayed"] > 0
