@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--ef", type=int, default=128)
     ap.add_argument("--per-cluster", type=int, default=1000)
     ap.add_argument("--mode", choices=["shard", "replica"], default="shard")
+    ap.add_argument("--row-dtype", choices=["f32", "bf16"], default="f32",
+                    help="storage type of the embedding rows (bf16: rows rounded to bf16, stored as "
+                         "such, arithmetic still f32 on the widened values; not the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-replica", action="store_true",
                     help="multi-GPU shard runs: skip the extra replica-mode measurement")
@@ -169,6 +172,10 @@ def main():
         # ---------------- setup (untimed): data, graph, index upload, queries, ground truth
         t0 = time.time()
         x = synth.make_rows(N, d, lo, n_local, per_cluster=args.per_cluster, device=dev)
+        x16 = None
+        if args.row_dtype == "bf16":
+            x16 = x.to(torch.bfloat16)       # the stored rows
+            x = x16.to(torch.float32)        # their exact f32 images: graph, truth and CPU baseline use these
         torch.cuda.synchronize()
         log(f"rows [{lo},{hi}) generated in {time.time() - t0:.1f}s")
         t0 = time.time()
@@ -180,7 +187,10 @@ def main():
         cfg = ia.LeannConfig.paper_default()
         idx = ia.LeannIndex.from_device_csr(offsets.data_ptr(), neighbours.data_ptr(), n_local, entry,
                                             d, cfg, device=local_rank)
-        idx.set_embeddings(None, device_ptr=x.data_ptr(), n=n_local, d=d)
+        if x16 is not None:
+            idx.set_embeddings_bf16(None, device_ptr=x16.data_ptr(), n=n_local, d=d)
+        else:
+            idx.set_embeddings(None, device_ptr=x.data_ptr(), n=n_local, d=d)
         log(f"index resident in {time.time() - t0:.1f}s")
 
         nb_batches = max(1, min(args.distinct_batches, args.steps + args.warmup))
@@ -299,14 +309,15 @@ def main():
         queries_per_step = nq if (world == 1 or shard_mode) else nq * world
         value = queries_per_step * args.steps / elapsed
         kernel_ms = agg["kernel_ms"] / max(args.steps, 1)
-        bytes_per_launch = algorithmic_bytes(agg, d, k) / max(args.steps, 1)
+        bytes_per_launch = algorithmic_bytes(agg, d, k, 2 if args.row_dtype == 'bf16' else 4) / max(args.steps, 1)
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        agg_gbs = algorithmic_bytes(agg, d, k) / elapsed / 1e9
+        agg_gbs = algorithmic_bytes(agg, d, k, 2 if args.row_dtype == 'bf16' else 4) / elapsed / 1e9
         # HBM bytes per launch come from a separate rocprofv3 --pmc FETCH_SIZE pass (counters cannot be
         # read from inside this process); the committed measurement applies to the headline workload only
         traffic_env = os.environ.get("ISL_TRAFFIC_BYTES")
         traffic_src = None
-        if not traffic_env and world == 1 and (N, d, nq, ef, k) == (10_000_000, 768, 1024, 128, 10):
+        if (not traffic_env and world == 1 and args.row_dtype == 'f32'
+                and (N, d, nq, ef, k) == (10_000_000, 768, 1024, 128, 10)):
             try:
                 with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch.json")) as fh:
                     traffic_env = str(json.load(fh)["search"]["hbm_bytes_per_launch"])
@@ -329,7 +340,7 @@ def main():
             "data": "synthetic",
             "recall_at_10": round(recall, 4),
             "config": {
-                "workload": f"{N} x {d} f32 rows resident in HBM (in-memory provider), hierarchical "
+                "workload": f"{N} x {d} {args.row_dtype} rows resident in HBM (in-memory provider), hierarchical "
                             f"Gaussian mixture, graph deg<= 60 (mean {gst['deg_mean']:.1f}), "
                             f"query batch {nq}, k={k}, ef={ef}, cosine",
                 "nodes": N, "dim": d, "query_batch": nq, "k": k, "ef": ef,
