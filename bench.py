@@ -369,6 +369,18 @@ def main():
                 "algorithmic_bytes_per_launch": round(bytes_per_launch, 0),
             },
         }
+        if world == 1:
+            # the boundary also takes host buffers (isl_search_batch): PCIe both ways, one
+            # synchronous call at a time -- reported for context, never the headline value
+            qh = qsets[0].cpu().numpy()
+            idx.search_batch(qh, k, ef)
+            t1 = time.perf_counter()
+            for _ in range(5):
+                idx.search_batch(qh, k, ef)
+            dt = time.perf_counter() - t1
+            result["host_pointer_path"] = {
+                "value": round(5 * nq / dt, 2), "unit": "queries/s", "ms_per_call": round(dt / 5 * 1e3, 3),
+                "note": "isl_search_batch with host query/result buffers, synchronous calls (PCIe included)"}
         return result, (x, offsets, neighbours, entry, qsets)
 
     result, (x, offsets, neighbours, entry, qsets) = measure(args.mode)
