@@ -24,7 +24,7 @@ __all__ = [
     "batch_calculate", "calculate", "calculate_squared", "normalize_rows", "distance_matrix",
     "bruteforce_topk", "merge_topk", "merge_service",
     "device_count", "HnswGraph", "SearchConfig", "Searcher", "MultiIndexSearcher",
-    "mean_pool_normalize", "BertConfig", "CandleEmbedder", "IndexMetadata",
+    "mean_pool_normalize", "service_search", "BertConfig", "CandleEmbedder", "IndexMetadata",
 ]
 
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -814,6 +814,30 @@ class MultiIndexSearcher:
 
     def search(self, query):
         return self.search_batch(_f32(query).reshape(1, -1))[0]
+
+
+# -------------------------------------------------------- indexer/service.rs
+def service_search(embedder, indexes, input_ids, attention_mask, top_k: int, device: int = 0):
+    """The device side of IndexerService::search_with_embeddings (indexer/service.rs:747-801) after
+    tokenisation: embed the query (embed_texts_raw), search every index's HnswGraph with
+    ef = max(top_k, 100) (:781), drop ids without a file entry, score = 1 - distance, sort by
+    score descending, truncate.  `indexes`: list of (name, HnswGraph, number_of_files).
+    Returns [(score, name, id)]."""
+    q = embedder.embed(np.asarray(input_ids).reshape(1, -1),
+                       None, None if attention_mask is None else np.asarray(attention_mask).reshape(1, -1))
+    ef = max(top_k, 100)
+    nl = len(indexes)
+    if nl == 0:
+        return []
+    ids = np.zeros((nl, 1, max(top_k, 1)), dtype=np.uint64)
+    dist = np.zeros((nl, 1, max(top_k, 1)), dtype=np.float32)
+    cnt = np.zeros((nl, 1), dtype=np.uint32)
+    for li, (_, graph, _) in enumerate(indexes):
+        a, b = graph.search_batch(q, top_k, ef)[0]
+        ids[li, 0, :len(a)], dist[li, 0, :len(a)], cnt[li, 0] = a, b, len(a)
+    files = np.array([f for _, _, f in indexes], dtype=np.uint64)
+    mi, ms, src, mc = merge_service(ids, dist, cnt, top_k, files_len=files, device=device)
+    return [(float(ms[0, j]), indexes[int(src[0, j])][0], int(mi[0, j])) for j in range(int(mc[0]))]
 
 
 # ------------------------------------------- embedding/candle_provider.rs

@@ -167,3 +167,33 @@ def test_recompute_provider_keeps_rows_when_asked(orc):
     second = idx.last_stats()
     assert a[0].tolist() == b[0].tolist() and first["encoded_nodes"] > 0
     assert second["encoded_nodes"] == 0 and second["recompute_rounds"] == 1
+
+
+# --------------------------------------------- indexer/service.rs:747-801, device side end to end
+def test_service_search_composition(orc):
+    import test_gpu_hnsw as th
+    cfg = dict(vocab_size=300, hidden=64, layers=2, heads=4, intermediate=128, max_position=16, type_vocab=2)
+    w = bert_ref.random_weights(cfg, seed=45, std=0.2)
+    enc = ia.CandleEmbedder(to_cfg(cfg), w, normalize=True)
+    rng = np.random.default_rng(12)
+    indexes, oracles = [], []
+    for name, n, seed in (("repo-a", 300, 1), ("repo-b", 200, 2)):
+        tok = rng.integers(1, 300, (n, 10))
+        emb = enc.embed(tok.astype(np.int64))
+        _, h, g = th.build(orc, n, 64, seed, m=8, m0=16, ef_construction=60, vectors=emb)
+        files = n - 7  # the last ids have no file entry (stored.files.get(id) == None, :788)
+        indexes.append((name, g, files))
+        oracles.append((name, h, files))
+    qtok = rng.integers(1, 300, 10)
+    got = ia.service_search(enc, indexes, qtok, np.ones(10, np.float32), top_k=5)
+    q = enc.embed(qtok.reshape(1, -1).astype(np.int64))[0]
+    li, ld = [], []
+    for _, h, files in oracles:
+        r = h.search(q, 5, 100)  # ef = max(top_k, 100), :781
+        keep = r.ids < files
+        li.append(r.ids[keep])
+        ld.append(r.dist[keep])
+    st, ei, es, esrc = orc.service_merge(li, ld, 5)
+    assert st == 0 and len(got) == ei.size
+    assert [(n, i) for _, n, i in got] == [(oracles[int(s)][0], int(i)) for s, i in zip(esrc, ei)]
+    assert np.array([s for s, _, _ in got], np.float32).view(np.uint32).tolist() == es.view(np.uint32).tolist()
