@@ -418,3 +418,17 @@ def test_bf16_rows_ties_take_the_exact_kernel(orc):
     idx.set_embeddings_bf16(bits)
     st, _ = assert_same_search(orc, idx, csr, rows, rows[:16], 10, 30)
     assert st["exact_path"] + st["replayed"] > 0
+
+
+def test_randomised_differential_slice(orc):
+    """A fixed slice of tools/fuzz_parity.py (random graphs / vectors / metrics / ef / k / pruning,
+    a third of the cases with quantised vectors so that equal distances are everywhere)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+    rng = np.random.default_rng(2024)
+    exact = 0
+    for case in range(120):
+        exact += fuzz_parity.one_case(rng, case)["exact_path"]
+    assert exact > 0  # the slice reaches the heap-exact kernel too

@@ -1,0 +1,104 @@
+"""Randomised differential test of the search path: the HIP kernels (through the C ABI) against
+the CPU oracle on random graphs, vectors (optionally quantised so that equal distances are
+common), metrics, ef / k, pruning settings.  Ids, distance bits, result counts and the work
+counters must all match.  Runs for `--seconds` on the GPU box:
+
+    python tools/fuzz_parity.py --seconds 120 [--seed 0]
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+
+import numpy as np
+
+import islands_amd as ia
+import oracle as orc
+from _data import clustered_vectors, knn_graph, random_csr, uniform_vectors
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def one_case(rng, case):
+    n = int(rng.choice([30, 200, 900, 2500]))
+    d = int(rng.choice([3, 8, 17, 32, 100, 768]))
+    if d == 768:
+        n = min(n, 900)
+    seed = int(rng.integers(1 << 30))
+    vec = clustered_vectors(n, d, seed) if rng.random() < 0.5 else uniform_vectors(n, d, seed)
+    quant = rng.random()
+    if quant < 0.3:  # coarse values -> many exactly equal distances
+        vec = np.round(vec * 2) / 2
+        vec[np.abs(vec).sum(1) == 0, 0] = 1.0
+    elif quant < 0.4:  # duplicated rows
+        vec[n // 2:] = vec[:n - n // 2]
+    vec = vec.astype(np.float32)
+    deg = int(rng.choice([4, 12, 30, 60, 64]))
+    if rng.random() < 0.5 and n >= 64:
+        off, nb = knn_graph(vec, min(deg, n - 1), seed)
+    else:
+        off, nb = random_csr(n, min(deg, n - 1), seed, dup=rng.random() < 0.2)
+    metric = int(rng.integers(0, 4))
+    ef = int(rng.choice([1, 2, 7, 33, 64, 100, 128, 200, 300]))
+    k = int(rng.choice([1, 3, 10, 50]))
+    ratio = float(rng.choice([0.0, 0.0, 0.3, 0.8]))
+    strategy = int(rng.integers(0, 2))
+    entry = int(rng.integers(0, n))
+    nq = 24
+    q = (vec[rng.integers(0, n, nq)] + (rng.random((nq, d), dtype=np.float32) - 0.5) *
+         np.float32(rng.choice([0.0, 0.05, 0.5]))).astype(np.float32)
+    levels = np.zeros(n, np.uint64)
+    degs = (off[1:] - off[:-1]).astype(np.uint64)
+    csr = orc.Csr(node_offsets=off, neighbors=nb, levels=levels, entry_point=entry, max_level=0,
+                  degree_counts=degs)
+    cfg = ia.LeannConfig(metric=ia.DistanceMetric(metric), prune_ratio=ratio,
+                         pruning_strategy=ia.PruningStrategy(strategy))
+    g = ia.CsrGraph(node_offsets=off, neighbors=nb, levels=levels, entry_point=entry, max_level=0,
+                    num_nodes=n, degree_counts=degs)
+    idx = ia.LeannIndex.from_csr(g, cfg, dimension=d)
+    idx.upload(0)
+    idx.set_embeddings(vec)
+    ids, dist, cnt = idx.search_batch(q, k, ef)
+    st = idx.last_stats()
+    tot = {"expansions": 0, "edges": 0, "evals": 0, "pushes": 0}
+    desc = f"case {case}: n={n} d={d} deg={deg} metric={metric} ef={ef} k={k} prune={ratio}/{strategy} quant={quant:.2f}"
+    for i in range(nq):
+        r = orc.leann_search(csr, vec, q[i], k, ef, metric=metric, prune_ratio=ratio, strategy=strategy)
+        assert r.status == 0, desc
+        c = int(cnt[i])
+        assert c == r.ids.size, (desc, i, c, r.ids.size)
+        assert ids[i, :c].tolist() == r.ids.tolist(), (desc, i, ids[i, :c], r.ids)
+        assert bits(dist[i, :c]).tolist() == bits(r.dist).tolist(), (desc, i)
+        for f in tot:
+            tot[f] += r.counters[f]
+    # the device removes repeated ids inside a row on upload: edges may differ then, the rest not
+    for f in ("expansions", "evals", "pushes"):
+        assert st[f] == tot[f], (desc, f, st[f], tot[f])
+    return st
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    orc.build()
+    rng = np.random.default_rng(args.seed)
+    t0, case, exact, replay = time.time(), 0, 0, 0
+    while time.time() - t0 < args.seconds:
+        st = one_case(rng, case)
+        exact += st["exact_path"]
+        replay += st["replayed"]
+        case += 1
+        if case % 20 == 0:
+            print(f"{case} cases ok ({exact} queries via the exact kernel, {replay} replayed)", flush=True)
+    print(f"fuzz ok: {case} cases, {case * 24} queries, {exact} via the exact kernel, {replay} replayed")
+
+
+if __name__ == "__main__":
+    main()
