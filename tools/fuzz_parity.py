@@ -82,22 +82,83 @@ def one_case(rng, case):
     return st
 
 
+def hnsw_case(rng, case):
+    """HnswGraph::search facade: graph built by the oracle's restatement of insert()."""
+    from _data import random_levels
+    n = int(rng.choice([1, 40, 300, 800]))
+    d = int(rng.choice([4, 16, 48]))
+    seed = int(rng.integers(1 << 30))
+    v = uniform_vectors(n, d, seed)
+    if rng.random() < 0.3:
+        v = (np.round(v * 2) / 2).astype(np.float32)
+        v[np.abs(v).sum(1) == 0, 0] = 1.0
+    m = int(rng.choice([4, 8, 16]))
+    metric = int(rng.integers(0, 4))
+    h = orc.Hnsw(m=m, m0=2 * m, ef_construction=int(rng.choice([20, 60])), metric=metric)
+    lv = random_levels(n, m, seed + 1)
+    for i in range(n):
+        st, _ = h.insert(v[i], int(lv[i]))
+        assert st == 0
+    layers = [[(h.neighbors(i, L) or []) for i in range(n)] for L in range(h.max_level + 1)]
+    g = ia.HnswGraph(v, layers, [h.level(i) for i in range(n)], h.entry_point, h.max_level, m=m, m0=2 * m,
+                     ef_construction=20, metric=ia.DistanceMetric(metric))
+    k, ef = int(rng.choice([1, 5, 20])), int(rng.choice([1, 10, 64, 150]))
+    q = (v[rng.integers(0, n, 16)] + (rng.random((16, d), dtype=np.float32) - 0.5) *
+         np.float32(rng.choice([0.0, 0.3]))).astype(np.float32)
+    got = g.search_batch(q, k, ef)
+    for i in range(16):
+        r = h.search(q[i], k, ef)
+        assert got[i][0].tolist() == r.ids.tolist(), (case, n, d, m, metric, k, ef, i)
+        assert bits(got[i][1]).tolist() == bits(r.dist).tolist(), (case, i)
+    return g.last_stats()
+
+
+def build_case(rng, case):
+    """isl_index_build with batch = 1 against the oracle's restatement of LeannIndex::build."""
+    from _data import random_levels
+    n = int(rng.choice([2, 60, 400, 900]))
+    d = int(rng.choice([4, 24, 64]))
+    seed = int(rng.integers(1 << 30))
+    v = uniform_vectors(n, d, seed) if rng.random() < 0.6 else clustered_vectors(n, d, seed)
+    if rng.random() < 0.25:
+        v = (np.round(v * 2) / 2).astype(np.float32)
+        v[np.abs(v).sum(1) == 0, 0] = 1.0
+    m0 = int(rng.choice([4, 12, 32, 60]))
+    cfg = ia.LeannConfig(m=max(2, m0 // 2), m0=m0, ef_construction=int(rng.choice([m0, 2 * m0, 128])),
+                         metric=ia.DistanceMetric(int(rng.integers(0, 4))),
+                         hub_percentile=float(rng.choice([0.02, 0.1, 0.5])),
+                         high_degree_pruning=bool(rng.random() < 0.8))
+    levels = random_levels(n, max(2, cfg.m), seed + 5) if rng.random() < 0.5 else None
+    csr = orc.leann_build(v, m=cfg.m, m0=cfg.m0, ef_construction=cfg.ef_construction, metric=int(cfg.metric),
+                          high_degree_pruning=cfg.high_degree_pruning, hub_percentile=cfg.hub_percentile,
+                          levels=levels)
+    g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels,
+                    entry_point=csr.entry_point, max_level=csr.max_level, num_nodes=csr.num_nodes,
+                    degree_counts=csr.degree_counts)
+    want = ia.LeannIndex.from_csr(g, cfg, dimension=d).to_bytes()
+    got = ia.LeannIndex.build(v, cfg, levels=levels, batch=1).to_bytes()
+    assert got == want, (case, n, d, m0, cfg)
+    return {"exact_path": 0, "replayed": 0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--mode", choices=["leann", "hnsw", "build"], default="leann")
     args = ap.parse_args()
     orc.build()
     rng = np.random.default_rng(args.seed)
     t0, case, exact, replay = time.time(), 0, 0, 0
+    fn = {"leann": one_case, "hnsw": hnsw_case, "build": build_case}[args.mode]
     while time.time() - t0 < args.seconds:
-        st = one_case(rng, case)
+        st = fn(rng, case)
         exact += st["exact_path"]
         replay += st["replayed"]
         case += 1
         if case % 20 == 0:
             print(f"{case} cases ok ({exact} queries via the exact kernel, {replay} replayed)", flush=True)
-    print(f"fuzz ok: {case} cases, {case * 24} queries, {exact} via the exact kernel, {replay} replayed")
+    print(f"fuzz {args.mode} ok: {case} cases, {exact} queries via the exact kernel, {replay} replayed")
 
 
 if __name__ == "__main__":
