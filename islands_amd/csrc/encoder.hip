@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -165,6 +166,138 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__
   }
 }
 
+// BertSelfAttention on the matrix cores for head sizes 32 and 64: one wave per (sequence, head)
+// and block of 64 queries.  The transposed problem is computed so that the probabilities never
+// leave the registers: S^T = K Q^T (rows = keys, columns = queries) with v_mfma_f32_32x32x2_f32
+// puts a query's 64 scores into one lane pair (lane l and l^32 hold column l%32), so the
+// softmax is lane-local plus one exchange, and the accumulator registers of S^T are exactly the
+// B operand of O^T = V^T P^T once the contraction index is enumerated in the order the
+// accumulator holds it (register 4a+b of lane l holds key 8a + 4(l/32) + b).  Keys are walked
+// in blocks of 64 with an online softmax (running max / sum per query).  Same arithmetic as
+// the VALU kernel up to summation order: q.k / sqrt(dh) + (1 - mask[key]) * f32::MIN.
+template <int DH>
+__global__ __launch_bounds__(64) void attention_mfma_kernel(const float* __restrict__ qkv,
+                                                            const float* __restrict__ mask, uint32_t L,
+                                                            uint32_t heads, float* __restrict__ ctx) {
+  constexpr int LD = DH + 1;   // tile pitch: conflict-free column reads
+  constexpr int CF = DH / 32;  // 32-wide blocks of the head dimension
+  __shared__ float Ta[64 * LD];  // Q block, later the V block
+  __shared__ float Tb[64 * LD];  // K block
+  const uint32_t lane = threadIdx.x, c32 = lane & 31, kh = lane >> 5;
+  const uint32_t b = blockIdx.x / heads, hd = blockIdx.x % heads;
+  const uint32_t h = heads * DH, ld = 3 * h;
+  const uint32_t q0 = blockIdx.y * 64;
+  const float inv_scale = sqrtf((float)DH);
+  constexpr int LPR = DH / 4;  // lanes per row when staging with float4 loads
+  auto stage = [&](float* T, uint32_t row0, uint32_t which) {  // rows row0.. of Q (0) / K (1) / V (2)
+    for (uint32_t rr = lane / LPR; rr < 64; rr += 64 / LPR) {
+      const uint32_t c = (lane % LPR) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + rr < L)
+        v = *reinterpret_cast<const float4*>(qkv + ((uint64_t)b * L + row0 + rr) * ld + which * h + hd * DH + c);
+      T[rr * LD + c] = v.x; T[rr * LD + c + 1] = v.y; T[rr * LD + c + 2] = v.z; T[rr * LD + c + 3] = v.w;
+    }
+  };
+  floatx16 o[CF][2];
+#pragma unroll
+  for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+    for (int qf = 0; qf < 2; ++qf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[cf][qf][r] = 0.0f;
+  float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.0f, 0.0f};
+  for (uint32_t j0 = 0; j0 < L; j0 += 64) {
+    __syncthreads();
+    stage(Ta, q0, 0);
+    stage(Tb, j0, 1);
+    __syncthreads();
+    // S^T[j][q] = sum_c K[j][c] Q[q][c]
+    floatx16 sT[2][2];
+#pragma unroll
+    for (int jf = 0; jf < 2; ++jf)
+#pragma unroll
+      for (int qf = 0; qf < 2; ++qf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sT[jf][qf][r] = 0.0f;
+#pragma unroll 4
+    for (int kk = 0; kk < DH / 2; ++kk) {
+      const float a0 = Tb[c32 * LD + 2 * kk + kh], a1 = Tb[(32 + c32) * LD + 2 * kk + kh];
+      const float b0 = Ta[c32 * LD + 2 * kk + kh], b1 = Ta[(32 + c32) * LD + 2 * kk + kh];
+      sT[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, sT[0][0], 0, 0, 0);
+      sT[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, sT[0][1], 0, 0, 0);
+      sT[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, sT[1][0], 0, 0, 0);
+      sT[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, sT[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+    stage(Ta, j0, 2);  // V block replaces the Q block
+    // scores: scale, mask bias per key (row), keys past L excluded
+    float cmax[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+    for (int jf = 0; jf < 2; ++jf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t j = j0 + 32 * jf + 8 * (r / 4) + 4 * kh + (r % 4);
+        const bool live = j < L;
+        const float bias = live ? (1.0f - mask[(uint64_t)b * L + j]) * -3.40282347e+38f : 0.0f;
+#pragma unroll
+        for (int qf = 0; qf < 2; ++qf) {
+          const float sv = live ? sT[jf][qf][r] / inv_scale + bias : -INFINITY;
+          sT[jf][qf][r] = sv;
+          cmax[qf] = fmaxf(cmax[qf], sv);
+        }
+      }
+    float corr[2];
+#pragma unroll
+    for (int qf = 0; qf < 2; ++qf) {
+      cmax[qf] = fmaxf(cmax[qf], __shfl_xor(cmax[qf], 32));
+      const float mnew = fmaxf(mrun[qf], cmax[qf]);
+      corr[qf] = expf(mrun[qf] - mnew);
+      mrun[qf] = mnew;
+      float ps = 0.0f;
+#pragma unroll
+      for (int jf = 0; jf < 2; ++jf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = expf(sT[jf][qf][r] - mnew);  // exp(-inf) = 0 for keys past L
+          sT[jf][qf][r] = pv;
+          ps += pv;
+        }
+      ps += __shfl_xor(ps, 32);
+      lrun[qf] = lrun[qf] * corr[qf] + ps;
+#pragma unroll
+      for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[cf][qf][r] *= corr[qf];
+    }
+    __syncthreads();  // V staged
+    // O^T[c][q] += sum_j V[j][c] P^T[j][q]; contraction slot (t, half) <-> key 32 jf + 8a + 4 half + b
+#pragma unroll
+    for (int jf = 0; jf < 2; ++jf)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const uint32_t j = 32 * jf + 8 * (t / 4) + 4 * kh + (t % 4);
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf) {
+          const float av = Ta[j * LD + 32 * cf + c32];
+          o[cf][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sT[jf][0][t], o[cf][0], 0, 0, 0);
+          o[cf][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sT[jf][1][t], o[cf][1], 0, 0, 0);
+        }
+      }
+  }
+  // ctx[q][c] = O^T[c][q] / l_q
+#pragma unroll
+  for (int qf = 0; qf < 2; ++qf) {
+    const uint32_t q = q0 + 32 * qf + c32;
+    if (q >= L) continue;
+    const float inv = 1.0f / lrun[qf];
+    float* op = ctx + ((uint64_t)b * L + q) * h + hd * DH;
+#pragma unroll
+    for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) op[32 * cf + 8 * (r / 4) + 4 * kh + (r % 4)] = o[cf][qf][r] * inv;
+  }
+}
+
 // masked mean pooling + optional L2 normalisation, candle_provider.rs:434-488; one wave per
 // sequence, lane j owns hidden units j, j+64, ...; sequential over the tokens.
 __global__ __launch_bounds__(64) void pool_kernel(const float* __restrict__ hid,
@@ -230,7 +363,10 @@ isl_status compute_forward(isl_encoder* e, bool has_tt, uint64_t B, uint64_t L, 
   for (const auto& ly : e->layers) {
     launch_gemm<0, false>(e->x, ly.wqkv, ly.bqkv, nullptr, e->qkv, M, 3 * h, h, st);
     dim3 ag((uint32_t)(B * c.heads), (uint32_t)((L + 63) / 64));
-    if (dh == 64) hipLaunchKernelGGL(attention_kernel<64>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
+    static const bool valu_attention = getenv("ISL_ATTENTION_VALU") != nullptr;
+    if (dh == 64 && !valu_attention) hipLaunchKernelGGL(attention_mfma_kernel<64>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
+    else if (dh == 32 && !valu_attention) hipLaunchKernelGGL(attention_mfma_kernel<32>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
+    else if (dh == 64) hipLaunchKernelGGL(attention_kernel<64>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
     else if (dh == 32) hipLaunchKernelGGL(attention_kernel<32>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
     else hipLaunchKernelGGL(attention_kernel<16>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
     launch_gemm<0, true>(e->ctx, ly.wo, ly.bo, e->x, e->t, M, h, h, st);
