@@ -41,7 +41,19 @@ isl_status fail_node(uint64_t node) {
   return fail(ISL_ERR_NODE_NOT_FOUND, "Node not found: %llu", (unsigned long long)node);
 }
 
+// The device checks (count, architecture) are made once per device and process; later calls only
+// select the device -- the search entry points run this on every call.
+namespace {
+struct DeviceInfo { int state = 0; int ncu = 256; };  // state: 0 unknown, 1 verified gfx950
+DeviceInfo g_devices[64];
+std::mutex g_devices_mu;
+}  // namespace
+
 isl_status use_device(int32_t device) {
+  if (device >= 0 && device < 64 && g_devices[device].state == 1) {
+    ISL_HIP(hipSetDevice(device));
+    return ISL_OK;
+  }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
     (void)hipGetLastError();
@@ -55,7 +67,16 @@ isl_status use_device(int32_t device) {
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(ISL_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
                 prop.gcnArchName);
+  if (device < 64) {
+    std::lock_guard<std::mutex> lock(g_devices_mu);
+    g_devices[device].ncu = prop.multiProcessorCount;
+    g_devices[device].state = 1;
+  }
   return ISL_OK;
+}
+
+int device_cu_count(int32_t device) {
+  return (device >= 0 && device < 64 && g_devices[device].state == 1) ? g_devices[device].ncu : 256;
 }
 
 void free_workspace(SearchWorkspace& ws) {

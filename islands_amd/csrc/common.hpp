@@ -42,6 +42,8 @@ isl_status fail_node(uint64_t node);
 
 // Selects `device` after checking that it exists and is a gfx950 part.
 isl_status use_device(int32_t device);
+// compute units of a device use_device has verified (256 before that)
+int device_cu_count(int32_t device);
 
 // ---- per-index device workspace for the search kernels ----
 struct SearchWorkspace {

@@ -1085,9 +1085,19 @@ size_t exact_lds(uint32_t ef, uint32_t d) {
 
 template <typename K>
 void launch_one(K kernel, uint32_t grid, size_t lds, hipStream_t st, const SearchParams& p) {
-  // more than 64 KiB of dynamic LDS needs the opt-in attribute
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // more than 64 KiB of dynamic LDS needs the opt-in attribute (set once per kernel and size)
+  if (lds > 64 * 1024) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, size_t>> done;
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    std::lock_guard<std::mutex> lock(mu);
+    bool have = false;
+    for (auto& e : done) have |= e.first == fn && e.second >= lds;
+    if (!have) {
+      (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      done.emplace_back(fn, lds);
+    }
+  }
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, st, p);
 }
 
@@ -1240,16 +1250,16 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
     return isl::fail(ISL_ERR_UNSUPPORTED, "ef = %u exceeds the device limit %u", ef, kMaxExactEf);
   if (nq > 0x7FFFFFFFull) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "too many queries");
 
-  int ncu = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, idx->device) == hipSuccess) ncu = prop.multiProcessorCount;
+  const int ncu = isl::device_cu_count(idx->device);
 
   FastGeom fg = fast_geometry(ef, (uint32_t)d);
   bool use_fast = ef <= 512 && ef >= 1 && idx->max_degree <= 64;
   // resident waves per CU: bounded by LDS (visited table + query) and by the kernel's VGPR
   // budget (<= 128 -> 4 per SIMD)
-  size_t cu_cap = 16;
-  if (const char* wc = getenv("ISL_WAVES_PER_CU")) cu_cap = (size_t)std::max(1, atoi(wc));
+  static const size_t cu_cap = [] {
+    const char* wc = getenv("ISL_WAVES_PER_CU");
+    return wc ? (size_t)std::max(1, atoi(wc)) : (size_t)16;
+  }();
   uint32_t per_cu = (uint32_t)std::min<size_t>(cu_cap, (160 * 1024) / fg.lds);
   if (per_cu == 0) use_fast = false;
   uint32_t slots = std::max<uint32_t>(1, (uint32_t)ncu * std::max<uint32_t>(per_cu, 1));
@@ -1291,7 +1301,8 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   p.ticket = ws.ticket;
   p.redo = ws.redo;
   if (ws.d_prof) { (void)hipFree(ws.d_prof); ws.d_prof = nullptr; }
-  if (getenv("ISL_DEBUG")) {
+  static const bool debug_env = getenv("ISL_DEBUG") != nullptr;
+  if (debug_env) {
     ISL_HIP(hipMalloc(&ws.d_prof, nq * 64));
     ISL_HIP(hipMemset(ws.d_prof, 0, nq * 64));
   }
