@@ -1071,6 +1071,8 @@ struct FastGeom {
 FastGeom fast_geometry(uint32_t ef, uint32_t d) {
   // visited capacity grows with ef (V is roughly 10-30 x ef); overflow goes to HBM
   uint32_t hbits = ef <= 64 ? 10 : ef <= 160 ? 11 : ef <= 320 ? 12 : 13;
+  static const int hbits_env = [] { const char* e = getenv("ISL_HBITS"); return e ? atoi(e) : 0; }();
+  if (hbits_env >= 8 && hbits_env <= 14) hbits = (uint32_t)hbits_env;  // experiments only
   // visited table, merge buffer, query (+ 64 bytes when d is not a multiple of 16: the operand
   // prefetch of direct_group may touch the rest of the last step)
   size_t lds = ((size_t)4 << hbits) + (size_t)(ef + kBatchMax) * 8 + (size_t)((d + 3) / 4 * 4) * 4 +
