@@ -145,7 +145,7 @@ template <int METRIC, int NI>
 __device__ __forceinline__ float group_distances(const float* __restrict__ emb, uint64_t stride,
                                                  uint32_t d, uint32_t rid, uint32_t g0, uint32_t Rg,
                                                  const float* qs, float* tile, float q_norm,
-                                                 float row_aux, uint64_t* prof3) {
+                                                 float row_aux) {
   const int lane = threadIdx.x;
   const int half = lane >> 5;        // which of the two rows of a load instruction
   const int col = (lane & 31) * 4;   // this lane's float4 inside the piece
@@ -214,7 +214,6 @@ __device__ __forceinline__ float group_distances(const float* __restrict__ emb, 
 #undef ISL_ADD_G
 #undef ISL_QUARTER
 #undef ISL_TERMS
-  uint64_t tw0 = prof3 ? __builtin_amdgcn_s_memrealtime() : 0;
   {
     const size_t poff = 0;
     ISL_FOR8(ISL_LOAD_A)
@@ -230,15 +229,12 @@ __device__ __forceinline__ float group_distances(const float* __restrict__ emb, 
   for (uint32_t t = 0; t < nT; t += 3) {
     ISL_FOR8(ISL_STORE_A)
     __syncthreads();
-    if (prof3 && t == 0) { uint64_t n_ = __builtin_amdgcn_s_memrealtime(); prof3[0] += n_ - tw0; tw0 = n_; }
     if (t + 3 < nT) {
       const size_t poff = (size_t)(t + 3) * PIECE;
       ISL_FOR8(ISL_LOAD_A)
     }
-    if (prof3 && t == 0) { uint64_t n_ = __builtin_amdgcn_s_memrealtime(); prof3[2] += n_ - tw0; tw0 = n_; }
     consume(t);
     __syncthreads();
-    if (prof3 && t == 0) { uint64_t n_ = __builtin_amdgcn_s_memrealtime(); prof3[1] += n_ - tw0; tw0 = n_; }
     if (t + 1 < nT) {
       ISL_FOR8(ISL_STORE_B)
       __syncthreads();
@@ -278,16 +274,16 @@ template <int METRIC>
 __device__ __forceinline__ float wave_distances(const float* __restrict__ emb, uint64_t stride,
                                                 uint32_t d, uint32_t rid, uint32_t R,
                                                 const float* qs, float* tile, float q_norm,
-                                                float row_aux = 0.0f, uint64_t* prof3 = nullptr) {
+                                                float row_aux = 0.0f) {
   const int lane = threadIdx.x;
   float result = 0.0f;
   for (uint32_t g0 = 0; g0 < R; g0 += GROUP) {
     const uint32_t Rg = R - g0 < (uint32_t)GROUP ? R - g0 : (uint32_t)GROUP;
     float dist;
-    if (Rg <= 2) dist = group_distances<METRIC, 1>(emb, stride, d, rid, g0, Rg, qs, tile, q_norm, row_aux, prof3);
-    else if (Rg <= 4) dist = group_distances<METRIC, 2>(emb, stride, d, rid, g0, Rg, qs, tile, q_norm, row_aux, prof3);
-    else if (Rg <= 8) dist = group_distances<METRIC, 4>(emb, stride, d, rid, g0, Rg, qs, tile, q_norm, row_aux, prof3);
-    else dist = group_distances<METRIC, 8>(emb, stride, d, rid, g0, Rg, qs, tile, q_norm, row_aux, prof3);
+    if (Rg <= 2) dist = group_distances<METRIC, 1>(emb, stride, d, rid, g0, Rg, qs, tile, q_norm, row_aux);
+    else if (Rg <= 4) dist = group_distances<METRIC, 2>(emb, stride, d, rid, g0, Rg, qs, tile, q_norm, row_aux);
+    else if (Rg <= 8) dist = group_distances<METRIC, 4>(emb, stride, d, rid, g0, Rg, qs, tile, q_norm, row_aux);
+    else dist = group_distances<METRIC, 8>(emb, stride, d, rid, g0, Rg, qs, tile, q_norm, row_aux);
     // quad j of this group computed row g0 + j: hand the value to lane g0 + j
     float moved = __shfl(dist, (4 * (lane - (int)g0)) & 63);
     if ((uint32_t)lane >= g0 && (uint32_t)lane < g0 + Rg) result = moved;

@@ -1,28 +1,27 @@
 // LEANN best-first search on gfx950: one 64-lane wavefront per query.
 //
 // Replaces LeannIndex::search_with_params / search_layer_recompute
-// (src/core/leann.rs:868-988) with the in-memory provider (leann.rs:104-159)
-// and DistanceMetric::calculate (src/core/distance.rs:37-122).
+// (src/core/leann.rs:868-988) over an EmbeddingProvider (in-memory rows, leann.rs:104-159, or the
+// recompute provider) with DistanceMetric::calculate (src/core/distance.rs:37-122); the same
+// kernels serve HnswGraph::search (src/core/hnsw.rs:458-504) and the graph builder's
+// construction searches.
 //
 // Parity design:
-//   * distances are computed in the reference's exact operation order -- one
-//     lane owns one candidate row and runs the strictly sequential f32 chain
-//     (separate multiply and add roundings, -ffp-contract=off), so every
-//     distance is bit-identical to the Rust scalar loop and every traversal
-//     decision (strict float compares at leann.rs:925,959) matches.
-//     Rows reach the lanes through an LDS tile that is filled with fully
-//     coalesced 16-byte loads (4 rows x 256 B per wave-instruction) and read
-//     back row-per-lane with conflict-free ds_read_b128 (row pitch 68 floats).
-//   * fast kernel: the result set R (<= ef entries, key = (OrderedFloat d, id))
-//     lives in registers as a sorted array spread over the wave; the candidate
-//     heap is implicit (live candidates are exactly the unexpanded entries of
-//     R).  Situations where the reference's BinaryHeap internals become
-//     observable (distance ties inside the returned prefix, or a tie between
-//     an evicted entry and the new worst) are detected and the query is re-run
-//     by the exact kernel.
-//   * exact kernel: emulates Rust's BinaryHeap push/pop/into_iter byte for byte
-//     (candidates in HBM scratch, results in LDS) for those queries, for
-//     ef > 512 and for adjacency rows longer than 64.
+//   * distances are computed in the reference's exact operation order: the strictly sequential
+//     f32 chain of a row (separate multiply and add roundings, -ffp-contract=off), so every
+//     distance is bit-identical to the Rust scalar loop and every traversal decision (strict
+//     float compares at leann.rs:925,959) matches.  The four lanes of a quad own one row, load 16
+//     of every 64 bytes of it straight from global memory into a register ring and exchange the
+//     products with DPP (device_common.cuh, direct_distances).
+//   * fast kernel: the result set R (<= ef entries, key = (OrderedFloat d, id)) lives in registers
+//     as a sorted array spread over the wave; the candidate heap is implicit (live candidates are
+//     exactly the unexpanded entries of R); the pushes of a hop are merged into R at once.
+//     Situations where the reference's BinaryHeap internals become observable (equal distances
+//     inside the returned prefix, or between an evicted entry and the new worst) are replayed from
+//     a push log or handed to the exact kernel.
+//   * exact kernel: emulates Rust's BinaryHeap push/pop/into_iter byte for byte (candidates in
+//     HBM scratch, results in LDS) for those queries, for ef > 512, for adjacency rows longer
+//     than 64 and for NaN / -0.0 distances.
 #include "device_common.cuh"
 #include "encoder.hpp"
 
@@ -538,7 +537,6 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
     uint32_t t_id = 0, tcount = 0;
     uint2* plog = p.plog + (size_t)qi * p.plog_cap;
     uint64_t tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0, tmark = 0, ngroups = 0, nhops_rows = 0;
-    uint64_t tw[3] = {0, 0, 0};
 #define ISL_MARK(acc) if (p.prof) { uint64_t now_ = __builtin_amdgcn_s_memrealtime(); acc += now_ - tmark; tmark = now_; }
 
     // entry point: provider.compute_embedding(entry) + distance, leann.rs:911-916
@@ -785,7 +783,6 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       if (p.prof) {
         p.prof[qi * 8 + 0] = tp0; p.prof[qi * 8 + 1] = tp1; p.prof[qi * 8 + 2] = tp2; p.prof[qi * 8 + 3] = tp3;
         p.prof[qi * 8 + 4] = ngroups; p.prof[qi * 8 + 5] = nhops_rows;
-        p.prof[qi * 8 + 6] = tw[2]; p.prof[qi * 8 + 7] = tw[1];
       }
       if (status == QS_REDO) {
         p.redo[atomicAdd(&p.ticket[1], 1u)] = qi;
@@ -1431,10 +1428,8 @@ isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws, uint32_
       grp += pr[i * 8 + 4];
       hr += pr[i * 8 + 5];
     }
-    double w0 = 0, w1 = 0;
-    for (uint64_t i = 0; i < nq; i++) { w0 += pr[i * 8 + 6] / 100.0; w1 += pr[i * 8 + 7] / 100.0; }
-    fprintf(stderr, "[isl] per query: %.1f hops with new rows, %.1f row groups of <=16; per group: first piece "
-            "landed+stored after %.2f us, one piece consumed in %.2f us\n", hr / nq, grp / nq, w0 / grp, w1 / grp);
+    fprintf(stderr, "[isl] per query: %.1f hops with new rows, %.1f distance passes of <= 16 rows\n", hr / nq,
+            grp / nq);
     fprintf(stderr, "[isl] mean us per query by phase: select+adjacency %.0f, visited %.0f, rows+distance %.0f, "
             "insert %.0f\n", sum[0] / nq, sum[1] / nq, sum[2] / nq, sum[3] / nq);
   }
