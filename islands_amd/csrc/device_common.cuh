@@ -41,6 +41,15 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
+// Ordering point for LDS traffic inside a ONE-WAVE workgroup: the LDS executes a wave's
+// instructions in order, so a plain __syncthreads() (s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier)
+// would only add a wait for every outstanding global store / load of the wave.  This keeps the
+// compiler from moving memory operations across it and emits no wait for vector memory.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // OrderedFloat<f32> total order mapped to unsigned: -0 == +0, NaN == NaN, NaN greatest.
 __device__ __forceinline__ uint32_t ordkey(float d) {
   if (d != d) return 0xFFFFFFFFu;

@@ -99,6 +99,7 @@ struct SearchParams {
   const uint32_t* const* layer_adj;
   uint32_t max_level;
   uint32_t hnsw_order;  // fast kernel: heaps ordered on the distance alone, equal distances -> exact kernel
+  uint32_t seq_max;     // hops with at most this many pushes insert one by one (cheaper than a merge)
   uint32_t* q_entry;    // [nq] layer-0 entry per query after the greedy descent (HnswGraph), or NULL
   uint32_t* q_evals;    // [nq] distance evaluations of the descent (+ 1 for the entry point)
 };
@@ -266,7 +267,7 @@ __device__ __forceinline__ int batch_insert(RSet<S>& rs, uint32_t ef, uint32_t w
     if (e < rs.len) { mk[e + c[s]] = rs.kd[s]; mi[e + c[s]] = rs.id[s]; }
   }
   if (inC) { mk[a + r] = nk; mi[a + r] = uid; }
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     const uint32_t e = (uint32_t)s * 64u + lane;
@@ -276,7 +277,7 @@ __device__ __forceinline__ int batch_insert(RSet<S>& rs, uint32_t ef, uint32_t w
     rs.kd[s] = live ? vk : KEY_MAX;
     rs.id[s] = live ? vi : KEY_MAX;
   }
-  __syncthreads();
+  wave_sync();
   rs.len = newlen;
   return BI_DONE;
 }
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       rs.len = 1;
       if (lane == 0) plog[0] = make_uint2(__float_as_uint(ed), entry);
       cP = 1;
-      __syncthreads();
+      wave_sync();
     }
 
     if (p.prof) tmark = __builtin_amdgcn_s_memrealtime();
@@ -644,9 +645,9 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       // compact the unvisited ids, CSR order preserved
       uint32_t rank = (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
       if (is_new) scratch[rank] = nid;
-      __syncthreads();
+      wave_sync();
       uint32_t uid = (uint32_t)lane < nu ? scratch[lane] : 0u;
-      __syncthreads();
+      wave_sync();
 
       uint32_t keep = prune_keep(p.prune_ratio, p.prune_strategy, nu, rs.len, ef);  // :944
       // compute_embeddings_batch, leann.rs:947: the first missing id fails the query
@@ -676,7 +677,9 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
         const uint32_t wk0 = full0 ? rs.key_at(ef - 1) : KEY_MAX;
         const uint64_t C = ballot(nk < wk0) & pending;
         if (!C) { ISL_MARK(tp3) continue; }
-        const int bi = batch_insert<S>(rs, ef, wk0, C, nk, uid, mbuf, p.hnsw_order != 0);
+        const int bi = ((uint32_t)__popcll(C) <= p.seq_max && !p.hnsw_order)
+                           ? BI_FALLBACK
+                           : batch_insert<S>(rs, ef, wk0, C, nk, uid, mbuf, p.hnsw_order != 0);
         if (bi == BI_TIE) { status = QS_REDO; payload = 6; break; }
         if (bi == BI_DONE) {
           const uint32_t rank = (uint32_t)__popcll(C & ((1ull << lane) - 1ull));
@@ -750,7 +753,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
     }
     if (status == QS_REPLAY) {
       __threadfence_block();
-      __syncthreads();
+      __syncthreads();  // rare path: keep the full wait before re-reading the push log
       // the search is over: the visited table's LDS (>= 4 KiB) becomes the replay's heap + stage
       float* res_d = reinterpret_cast<float*>(htab);
       uint32_t* res_i = htab + (ef + 1);
@@ -794,7 +797,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
     if (ovf) {  // leave the overflow table empty for the next query of this slot
       for (uint32_t i = lane; i < ocap; i += 64) otab[i] = EMPTY;
     }
-    __syncthreads();
+    wave_sync();
   }
 }
 
@@ -1328,6 +1331,8 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   p.hnsw_order = idx->is_hnsw ? 1u : 0u;
   p.q_entry = nullptr;
   p.q_evals = nullptr;
+  static const uint32_t seq_max_env = [] { const char* e = getenv("ISL_SEQ_MAX"); return e ? (uint32_t)atoi(e) : 0u; }();
+  p.seq_max = seq_max_env;
 
   ISL_HIP(hipMemsetAsync(ws.ticket, 0, 64, st));
   ISL_HIP(hipEventRecord(ws.ev0, st));
