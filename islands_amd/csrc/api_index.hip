@@ -273,6 +273,7 @@ void isl_index_free(isl_index* idx) {
   if (!idx) return;
   if (idx->device >= 0) {
     (void)hipSetDevice(idx->device);
+    if (idx->ell_owned) { (void)hipFree(idx->d_ell); (void)hipFree(idx->d_ell_deg); }
     if (idx->d_emb16) (void)hipFree(idx->d_emb16);
     if (idx->d_tokens) (void)hipFree(idx->d_tokens);
     if (idx->d_lens) (void)hipFree(idx->d_lens);

@@ -133,6 +133,7 @@ struct isl_index {
   uint32_t* d_ell = nullptr;      // [num_nodes][ell_w]
   uint32_t* d_ell_deg = nullptr;  // [num_nodes]
   uint32_t ell_w = 0;
+  bool ell_owned = false;         // the padded copy made at the first search (freed with the index)
 
   // recompute provider (EmbeddingProvider backed by the encoder, leann.rs:82-99): rows of d_emb
   // exist only where d_present has a bit; the search reports the rows it misses and the

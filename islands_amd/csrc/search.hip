@@ -589,17 +589,25 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
         break;
       }
       if ((uint64_t)cid >= p.num_nodes) continue;  // get_neighbors -> None, leann.rs:227-229
-      // adjacency: CSR, or fixed-width rows while the graph is under construction (build.hip)
-      uint64_t o0, o1;
-      if (p.ell_w) { o0 = (uint64_t)cid * p.ell_w; o1 = o0 + p.ell_deg[cid]; }
-      else { o0 = p.off[cid]; o1 = p.off[cid + 1]; }
-      uint32_t deg = (uint32_t)(o1 - o0);
+      // adjacency: fixed-width rows (the padded copy made at the first search, or the table of a
+      // graph under construction, build.hip) -- degree and ids are two independent loads, one
+      // memory round trip per hop; plain CSR (offset, then ids) otherwise
+      uint32_t deg, nid;
+      if (p.ell_w) {
+        const uint32_t slot = (uint32_t)lane < p.ell_w ? (uint32_t)lane : p.ell_w - 1u;
+        deg = p.ell_deg[cid];
+        const uint32_t raw = p.adj[(uint64_t)cid * p.ell_w + slot];
+        nid = (uint32_t)lane < deg ? raw : EMPTY;
+      } else {
+        const uint64_t o0 = p.off[cid], o1 = p.off[cid + 1];
+        deg = (uint32_t)(o1 - o0);
+        nid = ((uint32_t)lane < deg && deg <= 64) ? p.adj[o0 + lane] : EMPTY;
+      }
       cH += 1;
       cE += deg;
       if (deg == 0) continue;
       if (deg > 64) { status = QS_REDO; payload = 1; break; }  // long rows: exact kernel
       bool active = (uint32_t)lane < deg;
-      uint32_t nid = active ? p.adj[o0 + lane] : EMPTY;
 
       ISL_MARK(tp0)  // selection + adjacency fetch
       // visited.insert(n), leann.rs:933-937 (rows hold no duplicate ids on the device)
@@ -1235,6 +1243,18 @@ isl_status prepare_exact(const isl_index* idx, isl::SearchWorkspace& ws) {
   return ISL_OK;
 }
 
+// CSR -> 64 ids per node (EMPTY-padded) + degree; one wave per row
+__global__ void pad_rows_kernel(const uint64_t* __restrict__ off, const uint32_t* __restrict__ adj, uint64_t n,
+                                uint32_t* __restrict__ ell, uint32_t* __restrict__ deg) {
+  const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const uint64_t o0 = off[row];
+  const uint32_t d = (uint32_t)(off[row + 1] - o0);
+  ell[row * 64 + lane] = lane < d ? adj[o0 + lane] : EMPTY;  // rows longer than 64 never use the copy
+  if (lane == 0) deg[row] = d;
+}
+
 // Stream a call runs on.  OWN: the lane's non-blocking stream (host-pointer entry point).
 // USER: the caller's stream (NULL = legacy default stream, ordered after the caller's earlier
 // work on it, e.g. torch kernels that produced the queries).  OWN_AFTER_USER: the lane's stream,
@@ -1273,6 +1293,26 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   if (mode == StreamMode::OWN_AFTER_USER) {
     ISL_HIP(hipEventRecord(ws.ev_in, user_stream));
     ISL_HIP(hipStreamWaitEvent(ws.stream, ws.ev_in, 0));
+  }
+
+  if (use_fast && !idx->d_ell && idx->d_off && idx->num_nodes) {
+    // padded copy of the adjacency (64 ids per node + a degree array): 260 bytes per node buy the
+    // traversal one dependent memory round trip per hop
+    isl_index* mi = const_cast<isl_index*>(idx);
+    const uint64_t n = idx->num_nodes;
+    if (hipMalloc(&mi->d_ell, n * 64 * 4) == hipSuccess && hipMalloc(&mi->d_ell_deg, n * 4) == hipSuccess) {
+      hipLaunchKernelGGL(pad_rows_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, idx->d_off, idx->d_adj, n,
+                         mi->d_ell, mi->d_ell_deg);
+      ISL_HIP(hipGetLastError());
+      ISL_HIP(hipStreamSynchronize(st));  // once: searches on other lanes may start right away
+      mi->ell_w = 64;
+      mi->ell_owned = true;
+    } else {  // not enough memory: stay on the CSR
+      (void)hipGetLastError();
+      if (mi->d_ell) (void)hipFree(mi->d_ell);
+      mi->d_ell = nullptr;
+      mi->d_ell_deg = nullptr;
+    }
   }
 
   SearchParams p{};
