@@ -129,3 +129,31 @@ def test_compute_fails_loudly_without_gpu():
     with pytest.raises(ia.CoreError) as e:
         ia.calculate(ia.DistanceMetric.Cosine, [1, 2], [1, 2, 3])
     assert e.value.kind == "DimensionMismatch" and (e.value.expected, e.value.actual) == (2, 3)
+
+
+def test_every_compute_family_fails_loudly_without_gpu():
+    """The entry points added after the first search path -- encoder, recompute provider, builder,
+    HnswGraph facade, distance matrix, brute force, merges, pooling, PQ -- have no CPU path
+    either: on a box without a gfx950 each of them reports Device."""
+    import numpy as np
+    if ia.device_count() > 0:
+        pytest.skip("a GPU is present")
+    v = np.ones((4, 8), np.float32)
+    calls = [
+        lambda: ia.LeannIndex.build(v),
+        lambda: ia.CandleEmbedder(ia.BertConfig(vocab_size=10, hidden=32, layers=1, heads=2, intermediate=64,
+                                                max_position=8, type_vocab=1)),
+        lambda: ia.HnswGraph(v, [[[1], [0], [], []]], [0, 0, 0, 0], 0, 0),
+        lambda: ia.distance_matrix(ia.DistanceMetric.Cosine, v, v),
+        lambda: ia.bruteforce_topk(ia.DistanceMetric.Cosine, v, v, 2),
+        lambda: ia.batch_calculate(ia.DistanceMetric.Euclidean, v[0], v),
+        lambda: ia.normalize_rows(v),
+        lambda: ia.merge_topk(np.zeros((1, 1, 2), np.uint64), np.zeros((1, 1, 2), np.float32), np.ones((1, 1), np.uint32), 2),
+        lambda: ia.merge_service(np.zeros((1, 1, 2), np.uint64), np.zeros((1, 1, 2), np.float32), np.ones((1, 1), np.uint32), 2),
+        lambda: ia.mean_pool_normalize(np.zeros((1, 2, 8), np.float32), np.ones((1, 2), np.float32)),
+        lambda: ia.ProductQuantizer(8, np.zeros((2, 4, 4), np.float32)).encode(v),
+    ]
+    for i, call in enumerate(calls):
+        with pytest.raises(ia.CoreError) as e:
+            call()
+        assert e.value.kind == "Device", (i, e.value.kind, str(e.value))

@@ -55,6 +55,26 @@ __global__ __launch_bounds__(64) void k(float* out, unsigned long long* t, int i
         }
       }
     }
+  } else if (MODE == 3) {
+    const int r = lane >> 2, s = lane & 3;
+    const float* trow = lds + r * LD + 4 * s;
+    const float* qq = qv + 4 * s;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll 4
+      for (int j = 0; j < 128; j += 16) {
+        float4 x = *reinterpret_cast<const float4*>(trow + j);
+        float4 q = *reinterpret_cast<const float4*>(qq + j);
+        float p0 = q.x * x.x, p1 = q.y * x.y, p2 = q.z * x.z, p3 = q.w * x.w;
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) {
+          // the cross-lane move is taken off the dependent chain: v_mov_b32_dpp into a plain
+          // register (kept from folding into the add by the empty asm), then a plain v_add_f32
+          float t0 = qb(p0, ss), t1 = qb(p1, ss), t2 = qb(p2, ss), t3 = qb(p3, ss);
+          asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+          a0 += t0; a0 += t1; a0 += t2; a0 += t3;
+        }
+      }
+    }
   } else {
     const int r = lane >> 1, s = lane & 1;
     const float* trow = lds + r * LD + 4 * s;
@@ -85,7 +105,7 @@ template <int MODE> void run(float* out, unsigned long long* t, float* chk, cons
   hipError_t e = hipDeviceSynchronize();
   unsigned long long hh[2]; hipMemcpy(hh, t, 16, hipMemcpyDeviceToHost); unsigned long long h = hh[0];
   float c[64]; hipMemcpy(c, chk, 256, hipMemcpyDeviceToHost);
-  int stride = MODE == 0 ? 1 : (MODE == 1 ? 4 : 2);
+  int stride = MODE == 0 ? 1 : ((MODE == 1 || MODE == 3) ? 4 : 2);
   printf("%-28s grid %5d  %.2f cyc/elem %.3f ns/elem (err=%d) chk row0 %.9g row1 %.9g row15 %.9g\n", name, grid,
          (double)h / grid / (iters * 128.0), (double)hh[1] * 10.0 / grid / (iters * 128.0), (int)e, c[0], c[stride], c[15 * stride]);
 }
@@ -95,6 +115,7 @@ int main() {
     run<0>(out, t, chk, "lane-per-row (16 rows)", grid);
     run<1>(out, t, chk, "quad-per-row (16 rows)", grid);
     run<2>(out, t, chk, "pair-per-row (32 rows)", grid);
+    run<3>(out, t, chk, "quad, mov_dpp + plain add", grid);
   }
   return 0;
 }
