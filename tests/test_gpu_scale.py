@@ -96,3 +96,46 @@ def test_shard_merge_equals_host_merge(big):
         want = allv[:k]
         assert [w[2] for w in want] == mi[i, :mc[i]].tolist()
         assert [w[1] for w in want] == src[i, :mc[i]].tolist()
+
+
+def test_concurrent_callers_get_the_same_answers(big):
+    """Four host threads keep asynchronous searches in flight on one index (different batch
+    sizes and ef); every result must equal the synchronous answer for the same batch."""
+    import threading
+    dev, d = big["dev"], big["d"]
+    cases = [(96, 10, 64), (256, 5, 128), (33, 20, 40), (512, 10, 128)]
+    want = {}
+    for nq, k, ef in cases:
+        want[(nq, k, ef)] = run_device(big, big["q"][:nq].contiguous(), k, ef)
+    errors = []
+
+    def worker(case, reps):
+        nq, k, ef = case
+        q = big["q"][:nq].contiguous()
+        try:
+            for _ in range(reps):
+                outs = []
+                for _ in range(3):  # three in flight per thread -> twelve on the index
+                    ids = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+                    dist = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+                    cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+                    tok = big["idx"].search_batch_device_async(q.data_ptr(), nq, d, k, ef, ids.data_ptr(),
+                                                               dist.data_ptr(), cnt.data_ptr())
+                    outs.append((tok, ids, dist, cnt))
+                for tok, ids, dist, cnt in outs:
+                    big["idx"].wait(tok)
+                    w = want[case]
+                    if not (np.array_equal(ids.cpu().numpy(), w[0]) and
+                            np.array_equal(dist.cpu().numpy().view(np.uint32), w[1].view(np.uint32)) and
+                            np.array_equal(cnt.cpu().numpy(), w[2])):
+                        errors.append(("mismatch", case))
+        except Exception as ex:  # noqa: BLE001
+            errors.append((repr(ex), case))
+
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=worker, args=(c, 6)) for c in cases]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
