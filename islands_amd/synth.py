@@ -513,3 +513,55 @@ def graph_stats(offsets: torch.Tensor) -> dict:
     return {"nodes": int(deg.numel()), "edges": int(offsets[-1].item()),
             "deg_mean": float(deg.mean().item()), "deg_max": int(deg.max().item()),
             "deg_min": int(deg.min().item())}
+
+
+# ------------------------------------------------------------------ encoder weights
+def bert_weight_names(layers: int):
+    """Tensor names of a BERT checkpoint as candle's VarBuilder reads them
+    (src/core/embedding/candle_provider.rs:267-284)."""
+    names = ["embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
+             "embeddings.token_type_embeddings.weight", "embeddings.LayerNorm.weight",
+             "embeddings.LayerNorm.bias"]
+    for i in range(layers):
+        p = f"encoder.layer.{i}."
+        for lin in ("attention.self.query", "attention.self.key", "attention.self.value",
+                    "attention.output.dense"):
+            names += [p + lin + ".weight", p + lin + ".bias"]
+        names += [p + "attention.output.LayerNorm.weight", p + "attention.output.LayerNorm.bias",
+                  p + "intermediate.dense.weight", p + "intermediate.dense.bias",
+                  p + "output.dense.weight", p + "output.dense.bias",
+                  p + "output.LayerNorm.weight", p + "output.LayerNorm.bias"]
+    return names
+
+
+def bert_random_weights(cfg: dict, seed: int = 45, std: float = 0.02):
+    """Synthetic encoder weights ~ N(0, std^2), LayerNorm scale 1 + noise (SURVEY.md section 8d,
+    config 3: no checkpoint can be fetched offline)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    h, inter = cfg["hidden"], cfg["intermediate"]
+    w = {}
+    for name in bert_weight_names(cfg["layers"]):
+        if name == "embeddings.word_embeddings.weight":
+            shp = (cfg["vocab_size"], h)
+        elif name == "embeddings.position_embeddings.weight":
+            shp = (cfg["max_position"], h)
+        elif name == "embeddings.token_type_embeddings.weight":
+            shp = (cfg["type_vocab"], h)
+        elif "LayerNorm" in name:
+            shp = (h,)
+        elif name.endswith("intermediate.dense.weight"):
+            shp = (inter, h)
+        elif name.endswith("intermediate.dense.bias"):
+            shp = (inter,)
+        elif name.endswith("output.dense.weight") and "attention" not in name:
+            shp = (h, inter)
+        elif name.endswith(".weight"):
+            shp = (h, h)
+        else:
+            shp = (h,)
+        v = rng.standard_normal(shp).astype(np.float32) * np.float32(std)
+        if name.endswith("LayerNorm.weight"):
+            v = (np.float32(1.0) + v).astype(np.float32)
+        w[name] = v
+    return w

@@ -3,7 +3,7 @@ the CPU oracle on random graphs, vectors (optionally quantised so that equal dis
 common), metrics, ef / k, pruning settings.  Ids, distance bits, result counts and the work
 counters must all match.  Runs for `--seconds` on the GPU box:
 
-    python tools/fuzz_parity.py --seconds 120 [--seed 0]
+    python tests/fuzz_parity.py --seconds 120 [--seed 0]
 """
 import argparse
 import os
@@ -11,7 +11,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]  # run as a script
 
 import numpy as np
 

@@ -421,11 +421,8 @@ def test_bf16_rows_ties_take_the_exact_kernel(orc):
 
 
 def test_randomised_differential_slice(orc):
-    """A fixed slice of tools/fuzz_parity.py (random graphs / vectors / metrics / ef / k / pruning,
+    """A fixed slice of tests/fuzz_parity.py (random graphs / vectors / metrics / ef / k / pruning,
     a third of the cases with quantised vectors so that equal distances are everywhere)."""
-    import os
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_parity
     rng = np.random.default_rng(2024)
     exact = 0

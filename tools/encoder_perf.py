@@ -1,14 +1,14 @@
 import sys, os, time
-sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")]
+sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]
 import numpy as np
 import islands_amd as ia
-import bert_ref
+from islands_amd import synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 h = int(sys.argv[3]) if len(sys.argv) > 3 else 768
 layers = 6
 cfg = dict(vocab_size=30522, hidden=h, layers=layers, heads=12, intermediate=4 * h, max_position=512, type_vocab=2)
-w = bert_ref.random_weights(cfg, seed=45, std=0.02)
+w = synth.bert_random_weights(cfg, seed=45, std=0.02)
 enc = ia.CandleEmbedder(ia.BertConfig(**{k: cfg[k] for k in cfg}), w)
 rng = np.random.default_rng(44)
 ids = rng.integers(1, 30522, (B, L)).astype(np.int64)

@@ -14,13 +14,12 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+sys.path[:0] = [ROOT]
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np
 import torch
 
-import bert_ref  # weight naming / synthetic weights only
 import islands_amd as ia
 from islands_amd import synth
 
@@ -38,7 +37,7 @@ def main():
     N, L, h, layers = args.nodes, args.tokens, 768, 6
     cfg = dict(vocab_size=30522, hidden=h, layers=layers, heads=12, intermediate=3072,
                max_position=512, type_vocab=2)
-    enc = ia.CandleEmbedder(ia.BertConfig(**cfg), bert_ref.random_weights(cfg, seed=45, std=0.02))
+    enc = ia.CandleEmbedder(ia.BertConfig(**cfg), synth.bert_random_weights(cfg, seed=45, std=0.02))
     rng = np.random.default_rng(44)
     topics = rng.integers(1, cfg["vocab_size"], ((N + 999) // 1000, 8)).astype(np.uint16)
     tok = rng.integers(1, cfg["vocab_size"], (N, L)).astype(np.uint16)
