@@ -175,7 +175,7 @@ struct RSet {
     }
 #pragma unroll
     for (int s = S - 1; s >= 0; --s) {
-      if (pos >= 64u * (uint32_t)(s + 1)) break;  // uniform: this slot and the lower ones stay
+      if (pos >= 64u * (uint32_t)(s + 1)) continue;  // uniform: this slot stays as it is
       uint32_t uk = shr1_u(kd[s]);
       uint32_t ui = shr1_u(id[s]);
       if (s > 0) {  // lane 0 takes the last entry of the slot below
