@@ -330,6 +330,11 @@ void isl_encoder_free(isl_encoder* enc);
  * DimensionMismatch{expected, actual}. */
 isl_status isl_encoder_set_weight(isl_encoder* enc, const char* name, const float* data,
                                   uint64_t count, int32_t mem);
+/* Optional precision of the Linear layers: ISL_DTYPE_F32 (default) is the reference's float32
+ * model; ISL_DTYPE_BF16 rounds weights and GEMM inputs to bf16 (float32 accumulation on the bf16
+ * matrix cores) -- several times faster, embeddings differ from the float32 ones by about 1e-2
+ * relative.  Call after the weights are set (changing a weight afterwards needs a new call). */
+isl_status isl_encoder_set_precision(isl_encoder* enc, int32_t dtype);
 /* BertModel::forward(input_ids, token_type_ids, Some(attention_mask)), candle_provider.rs:429-432:
  * ids [B, L] (already padded per :385-402), token_type_ids NULL = zeros, attention_mask [B, L]
  * of 0.0 / 1.0, NULL = ones -> last hidden state [B, L, hidden]. */

@@ -940,6 +940,11 @@ class CandleEmbedder:
         v = _f32(value)
         _check(_ffi.lib().isl_encoder_set_weight(self._h, name.encode(), _ptr(v), v.size, MEM_HOST))
 
+    def set_precision(self, bf16: bool) -> None:
+        """float32 Linear layers (default, the reference's arithmetic) or bf16 inputs with float32
+        accumulation on the bf16 matrix cores; call after the weights are set."""
+        _check(_ffi.lib().isl_encoder_set_precision(self._h, 1 if bf16 else 0))
+
     def dimension(self) -> int:
         return self.config.hidden
 

@@ -118,6 +118,7 @@ SIGNATURES = {
     "isl_encoder_new": (i32, [P(BertConfigC), i32, P(C.c_void_p)]),
     "isl_encoder_free": (None, [C.c_void_p]),
     "isl_encoder_set_weight": (i32, [C.c_void_p, C.c_char_p, C.c_void_p, u64, i32]),
+    "isl_encoder_set_precision": (i32, [C.c_void_p, i32]),
     "isl_encoder_forward": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u64, u64,
                                   C.c_void_p, i32, C.c_void_p]),
     "isl_encoder_embed": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u64, u64, i32,

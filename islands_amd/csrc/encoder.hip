@@ -15,6 +15,7 @@
 #include "common.hpp"
 #include "encoder.hpp"
 #include "gemm_f32.cuh"
+#include "gemm_bf16.cuh"
 
 #include <algorithm>
 #include <cmath>
@@ -360,8 +361,11 @@ isl_status compute_forward(isl_encoder* e, bool has_tt, uint64_t B, uint64_t L, 
                      has_tt ? e->d_tt : nullptr, (uint32_t)L, (uint32_t)h, c.vocab_size, c.type_vocab,
                      e->word, e->pos, e->type, e->eln_w, e->eln_b, c.layer_norm_eps, e->x, e->d_flag);
   const uint32_t dh = c.hidden / c.heads;
-  for (const auto& ly : e->layers) {
-    launch_gemm<0, false>(e->x, ly.wqkv, ly.bqkv, nullptr, e->qkv, M, 3 * h, h, st);
+  const bool half = e->precision == ISL_DTYPE_BF16 && !e->layers16.empty() && h % 8 == 0 && I % 8 == 0;
+  for (size_t li = 0; li < e->layers.size(); ++li) {
+    const auto& ly = e->layers[li];
+    if (half) launch_gemm_bf16<0, false>(e->x, (const __bf16*)e->layers16[li].wqkv, ly.bqkv, nullptr, e->qkv, M, 3 * h, h, st);
+    else launch_gemm<0, false>(e->x, ly.wqkv, ly.bqkv, nullptr, e->qkv, M, 3 * h, h, st);
     dim3 ag((uint32_t)(B * c.heads), (uint32_t)((L + 63) / 64));
     static const bool valu_attention = getenv("ISL_ATTENTION_VALU") != nullptr;
     if (dh == 64 && !valu_attention) hipLaunchKernelGGL(attention_mfma_kernel<64>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
@@ -369,11 +373,18 @@ isl_status compute_forward(isl_encoder* e, bool has_tt, uint64_t B, uint64_t L, 
     else if (dh == 64) hipLaunchKernelGGL(attention_kernel<64>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
     else if (dh == 32) hipLaunchKernelGGL(attention_kernel<32>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
     else hipLaunchKernelGGL(attention_kernel<16>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
-    launch_gemm<0, true>(e->ctx, ly.wo, ly.bo, e->x, e->t, M, h, h, st);
+    if (half) launch_gemm_bf16<0, true>(e->ctx, (const __bf16*)e->layers16[li].wo, ly.bo, e->x, e->t, M, h, h, st);
+    else launch_gemm<0, true>(e->ctx, ly.wo, ly.bo, e->x, e->t, M, h, h, st);
     hipLaunchKernelGGL(ln_kernel, dim3((uint32_t)M), dim3(64), h * 4, st, e->t, (uint32_t)h, ly.ln1w, ly.ln1b, c.layer_norm_eps, e->x1);
-    if (c.gelu_tanh) launch_gemm<2, false>(e->x1, ly.wi, ly.bi, nullptr, e->inter, M, I, h, st);
-    else launch_gemm<1, false>(e->x1, ly.wi, ly.bi, nullptr, e->inter, M, I, h, st);
-    launch_gemm<0, true>(e->inter, ly.wo2, ly.bo2, e->x1, e->t, M, h, I, st);
+    if (half) {
+      if (c.gelu_tanh) launch_gemm_bf16<2, false>(e->x1, (const __bf16*)e->layers16[li].wi, ly.bi, nullptr, e->inter, M, I, h, st);
+      else launch_gemm_bf16<1, false>(e->x1, (const __bf16*)e->layers16[li].wi, ly.bi, nullptr, e->inter, M, I, h, st);
+      launch_gemm_bf16<0, true>(e->inter, (const __bf16*)e->layers16[li].wo2, ly.bo2, e->x1, e->t, M, h, I, st);
+    } else {
+      if (c.gelu_tanh) launch_gemm<2, false>(e->x1, ly.wi, ly.bi, nullptr, e->inter, M, I, h, st);
+      else launch_gemm<1, false>(e->x1, ly.wi, ly.bi, nullptr, e->inter, M, I, h, st);
+      launch_gemm<0, true>(e->inter, ly.wo2, ly.bo2, e->x1, e->t, M, h, I, st);
+    }
     hipLaunchKernelGGL(ln_kernel, dim3((uint32_t)M), dim3(64), h * 4, st, e->t, (uint32_t)h, ly.ln2w, ly.ln2b, c.layer_norm_eps, e->x);
   }
   ISL_HIP(hipGetLastError());
@@ -552,6 +563,38 @@ isl_status isl_encoder_set_weight(isl_encoder* e, const char* name, const float*
     return isl::fail_dim(want, count);
   }
   ISL_HIP(hipMemcpy(dst, data, count * 4, mem == ISL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice));
+  return ISL_OK;
+}
+
+// Optional reduced-precision mode of the Linear layers: ISL_DTYPE_BF16 rounds the weights (once,
+// here) and the activations (per GEMM) to bf16 and accumulates in float32 on the bf16 matrix
+// cores; ISL_DTYPE_F32 (default) is the reference's arithmetic.  Call after the weights are set.
+isl_status isl_encoder_set_precision(isl_encoder* e, int32_t dtype) {
+  if (!e) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "encoder is NULL");
+  if (dtype != ISL_DTYPE_F32 && dtype != ISL_DTYPE_BF16) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "unknown dtype");
+  ISL_TRY(isl::use_device(e->device));
+  std::lock_guard<std::mutex> lock(e->mu);
+  const uint64_t h = e->cfg.hidden, I = e->cfg.intermediate;
+  if (dtype == ISL_DTYPE_BF16) {
+    if (h % 8 || I % 8) return isl::fail(ISL_ERR_UNSUPPORTED, "bf16 mode needs hidden and intermediate sizes that are multiples of 8");
+    if (e->layers16.empty()) e->layers16.resize(e->layers.size());
+    for (size_t li = 0; li < e->layers.size(); ++li) {
+      const float* src[4] = {e->layers[li].wqkv, e->layers[li].wo, e->layers[li].wi, e->layers[li].wo2};
+      const uint64_t cnt[4] = {3 * h * h, h * h, I * h, h * I};
+      void** dst[4] = {&e->layers16[li].wqkv, &e->layers16[li].wo, &e->layers16[li].wi, &e->layers16[li].wo2};
+      for (int t = 0; t < 4; ++t) {
+        if (!*dst[t]) {
+          ISL_HIP(hipMalloc(dst[t], cnt[t] * 2));
+          e->owned.push_back(*dst[t]);
+        }
+        hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((uint32_t)((cnt[t] + 255) / 256)), dim3(256), 0, 0, src[t],
+                           (__bf16*)*dst[t], cnt[t]);
+      }
+    }
+    ISL_HIP(hipGetLastError());
+    ISL_HIP(hipDeviceSynchronize());
+  }
+  e->precision = dtype;
   return ISL_OK;
 }
 

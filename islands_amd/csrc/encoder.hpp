@@ -14,6 +14,10 @@ struct isl_encoder {
           *ln2w = nullptr, *ln2b = nullptr;
   };
   std::vector<Layer> layers;
+  // optional reduced-precision mode: bf16 copies of the Linear weights (same order as `layers`)
+  struct Layer16 { void *wqkv = nullptr, *wo = nullptr, *wi = nullptr, *wo2 = nullptr; };
+  std::vector<Layer16> layers16;
+  int32_t precision = 0;  // ISL_DTYPE_F32 / ISL_DTYPE_BF16
   std::vector<void*> owned;
   // workspace, grown on demand (tokens = sequences * padded length)
   uint64_t ws_tokens = 0;

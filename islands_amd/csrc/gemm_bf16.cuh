@@ -1,0 +1,134 @@
+// bf16-input GEMM on the matrix cores for the encoder's optional reduced-precision mode
+// (isl_encoder_set_precision): C[M,N] = A[M,K] W[N,K]^T + bias (+ GELU, + residual) with A in
+// float32 (rounded to bf16 while it is staged into LDS), W pre-converted to bf16, float32
+// accumulation in v_mfma_f32_32x32x16_bf16.  Same tiling idea as gemm_f32.cuh: 128x128 tile per
+// 256-thread workgroup, 64x64 per wave = 2x2 MFMA blocks, K in slabs of 64, the next slab
+// prefetched into registers.  Operand layout of the 32x32x16 MFMA: lane l supplies row (or
+// column) l % 32 and the 8 consecutive k values 8 * (l / 32) .. + 7 of each 16-wide k step.
+#pragma once
+
+#include "common.hpp"
+#include "gemm_f32.cuh"
+
+namespace isl_gemm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HBK = 64;          // k per slab
+constexpr int HLD = HBK + 8;     // LDS row pitch in bf16 (144 bytes: conflict-free 16-byte reads)
+
+template <int ACT, bool RES>
+__global__ __launch_bounds__(256) void gemm_tn_bf16(const float* __restrict__ A,
+                                                    const __bf16* __restrict__ W,
+                                                    const float* __restrict__ bias,
+                                                    const float* __restrict__ R, float* __restrict__ C,
+                                                    uint32_t M, uint32_t N, uint32_t K) {
+  __shared__ __attribute__((aligned(16))) __bf16 As[BM * HLD];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[BN * HLD];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const uint64_t m0 = (uint64_t)blockIdx.y * BM, n0 = (uint64_t)blockIdx.x * BN;
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  // A slab: 128 rows x 64 floats = 2048 float4 -> 8 per thread (row = idx / 16, 4-float column
+  // group = idx % 16); W slab: 128 rows x 64 bf16 = 1024 x 16 bytes -> 4 per thread (row = idx / 8)
+  float4 pa[8];
+  bf16x8 pb[4];
+  const bool edge = m0 + BM > M || n0 + BN > N || (K % HBK) != 0;
+  auto fetch = [&](uint32_t k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t idx = tid + 256u * i, r = idx >> 4, c = (idx & 15) * 4;
+      const bool out = edge && (m0 + r >= M || k0 + c >= K);  // K is a multiple of 8 (host check)
+      const uint64_t rr = (m0 + r < M) ? m0 + r : (uint64_t)M - 1;
+      const uint32_t kc = (k0 + c < K) ? k0 + c : 0u;
+      pa[i] = *reinterpret_cast<const float4*>(A + rr * K + kc);
+      if (out) pa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t idx = tid + 256u * i, r = idx >> 3, c = (idx & 7) * 8;
+      const bool out = edge && (n0 + r >= N || k0 + c >= K);
+      const uint64_t rr = (n0 + r < N) ? n0 + r : (uint64_t)N - 1;
+      const uint32_t kc = (k0 + c < K) ? k0 + c : 0u;
+      pb[i] = *reinterpret_cast<const bf16x8*>(W + rr * K + kc);
+      if (out) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pb[i][e] = (__bf16)0.0f;
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t idx = tid + 256u * i, r = idx >> 4, c = (idx & 15) * 4;
+      bf16x4 v;
+      v[0] = (__bf16)pa[i].x; v[1] = (__bf16)pa[i].y; v[2] = (__bf16)pa[i].z; v[3] = (__bf16)pa[i].w;
+      *reinterpret_cast<bf16x4*>(&As[r * HLD + c]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t idx = tid + 256u * i, r = idx >> 3, c = (idx & 7) * 8;
+      *reinterpret_cast<bf16x8*>(&Bs[r * HLD + c]) = pb[i];
+    }
+  };
+  fetch(0);
+  const uint32_t kh = lane >> 5, c32 = lane & 31;
+  for (uint32_t k0 = 0; k0 < K; k0 += HBK) {
+    stage();
+    __syncthreads();
+    if (k0 + HBK < K) fetch(k0 + HBK);
+#pragma unroll
+    for (int ks = 0; ks < HBK / 16; ++ks) {
+      const uint32_t ko = 16 * ks + 8 * kh;
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&As[(wm + c32) * HLD + ko]);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[(wm + 32 + c32) * HLD + ko]);
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&Bs[(wn + c32) * HLD + ko]);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Bs[(wn + 32 + c32) * HLD + ko]);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint64_t n = n0 + wn + j * 32 + c32;
+      if (n >= N) continue;
+      const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint64_t m = m0 + wm + i * 32 + 8 * (r / 4) + 4 * kh + (r % 4);
+        if (m >= M) continue;
+        float v = acc[i][j][r] + bv;
+        if (ACT == 1) v = gelu_erf_f(v);
+        if (ACT == 2) v = gelu_tanh_f(v);
+        if (RES) v += R[m * N + n];
+        C[m * N + n] = v;
+      }
+    }
+}
+
+template <int ACT, bool RES>
+void launch_gemm_bf16(const float* A, const __bf16* W, const float* bias, const float* R, float* C,
+                      uint64_t M, uint64_t N, uint64_t K, hipStream_t st) {
+  dim3 grid((uint32_t)((N + BN - 1) / BN), (uint32_t)((M + BM - 1) / BM));
+  hipLaunchKernelGGL((gemm_tn_bf16<ACT, RES>), grid, dim3(256), 0, st, A, W, bias, R, C, (uint32_t)M,
+                     (uint32_t)N, (uint32_t)K);
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (__bf16)src[i];
+}
+
+}  // namespace isl_gemm

@@ -197,3 +197,22 @@ def test_service_search_composition(orc):
     assert st == 0 and len(got) == ei.size
     assert [(n, i) for _, n, i in got] == [(oracles[int(s)][0], int(i)) for s, i in zip(esrc, ei)]
     assert np.array([s for s, _, _ in got], np.float32).view(np.uint32).tolist() == es.view(np.uint32).tolist()
+
+
+def test_bf16_linear_mode_is_close_and_switchable():
+    """Optional bf16 mode of the Linear layers: embeddings within 3e-2 (absolute, unit vectors) of
+    the float32 ones, cosine similarity to them above 0.999; switching back restores the float32
+    bits."""
+    cfg = dict(vocab_size=500, hidden=384, layers=6, heads=12, intermediate=1536, max_position=128, type_vocab=2)
+    w = bert_ref.random_weights(cfg, seed=45, std=0.08)
+    enc = ia.CandleEmbedder(to_cfg(cfg), w, normalize=True)
+    rng = np.random.default_rng(5)
+    ids, tt, mask = bert_ref.pad_batch([rng.integers(1, 500, n).tolist() for n in (70, 12, 33, 70)])
+    f32 = enc.embed(ids, tt, mask)
+    enc.set_precision(bf16=True)
+    b16 = enc.embed(ids, tt, mask)
+    assert not np.array_equal(f32, b16)
+    assert np.abs(f32 - b16).max() < 3e-2, np.abs(f32 - b16).max()
+    assert np.all((f32 * b16).sum(1) > 0.999)
+    enc.set_precision(bf16=False)
+    assert np.array_equal(enc.embed(ids, tt, mask).view(np.uint32), f32.view(np.uint32))

@@ -10,6 +10,8 @@ layers = 6
 cfg = dict(vocab_size=30522, hidden=h, layers=layers, heads=12, intermediate=4 * h, max_position=512, type_vocab=2)
 w = synth.bert_random_weights(cfg, seed=45, std=0.02)
 enc = ia.CandleEmbedder(ia.BertConfig(**{k: cfg[k] for k in cfg}), w)
+if os.environ.get("ISL_ENCODER_BF16"):
+    enc.set_precision(bf16=True)
 rng = np.random.default_rng(44)
 ids = rng.integers(1, 30522, (B, L)).astype(np.int64)
 mask = np.ones((B, L), np.float32)
