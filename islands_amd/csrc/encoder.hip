@@ -37,7 +37,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // LayerNorm of one token row held in LDS (`row`, h floats): biased variance of the centred
 // values, eps inside the square root (candle_nn::LayerNorm / torch.nn.LayerNorm).
 __device__ __forceinline__ void ln_row(const float* row, uint32_t h, const float* __restrict__ w,
-                                       const float* __restrict__ b, float eps, float* __restrict__ out) {
+                                       const float* __restrict__ b, float eps, float* __restrict__ out,
+                                       __bf16* __restrict__ out16 = nullptr) {
   const uint32_t lane = threadIdx.x;
   float s = 0.0f;
   for (uint32_t j = lane; j < h; j += 64) s += row[j];
@@ -46,7 +47,11 @@ __device__ __forceinline__ void ln_row(const float* row, uint32_t h, const float
   for (uint32_t j = lane; j < h; j += 64) { float c = row[j] - mean; v += c * c; }
   const float var = wave_sum(v) / (float)h;
   const float inv = 1.0f / sqrtf(var + eps);
-  for (uint32_t j = lane; j < h; j += 64) out[j] = (row[j] - mean) * inv * w[j] + b[j];
+  for (uint32_t j = lane; j < h; j += 64) {
+    const float y = (row[j] - mean) * inv * w[j] + b[j];
+    out[j] = y;
+    if (out16) out16[j] = (__bf16)y;  // bf16 mode: the copy the next GEMM reads
+  }
 }
 
 // BertEmbeddings: word + token_type + position -> LayerNorm.  One wave per token.
@@ -58,7 +63,8 @@ __global__ __launch_bounds__(64) void embed_ln_kernel(const int64_t* __restrict_
                                                       const float* __restrict__ type,
                                                       const float* __restrict__ w,
                                                       const float* __restrict__ b, float eps,
-                                                      float* __restrict__ out, uint32_t* flag) {
+                                                      float* __restrict__ out, uint32_t* flag,
+                                                      __bf16* __restrict__ out16) {
   extern __shared__ float row[];
   const uint64_t tok = blockIdx.x;
   const uint32_t p = (uint32_t)(tok % L);
@@ -71,19 +77,19 @@ __global__ __launch_bounds__(64) void embed_ln_kernel(const int64_t* __restrict_
   for (uint32_t j = threadIdx.x; j < h; j += 64)
     row[j] = word[(uint64_t)id * h + j] + type[(uint64_t)ty * h + j] + pos[(uint64_t)p * h + j];
   __syncthreads();
-  ln_row(row, h, w, b, eps, out + tok * h);
+  ln_row(row, h, w, b, eps, out + tok * h, out16 ? out16 + tok * h : nullptr);
 }
 
 // y = LayerNorm(a) (the residual is already added by the GEMM epilogue).  One wave per token.
 __global__ __launch_bounds__(64) void ln_kernel(const float* __restrict__ a, uint32_t h,
                                                 const float* __restrict__ w,
                                                 const float* __restrict__ b, float eps,
-                                                float* __restrict__ out) {
+                                                float* __restrict__ out, __bf16* __restrict__ out16) {
   extern __shared__ float row[];
   const uint64_t tok = blockIdx.x;
   for (uint32_t j = threadIdx.x; j < h; j += 64) row[j] = a[tok * h + j];
   __syncthreads();
-  ln_row(row, h, w, b, eps, out + tok * h);
+  ln_row(row, h, w, b, eps, out + tok * h, out16 ? out16 + tok * h : nullptr);
 }
 
 // BertSelfAttention for one (sequence, head) and 64 query rows per wave: lane i owns query row
@@ -179,7 +185,8 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__
 template <int DH>
 __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* __restrict__ qkv,
                                                             const float* __restrict__ mask, uint32_t L,
-                                                            uint32_t heads, float* __restrict__ ctx) {
+                                                            uint32_t heads, float* __restrict__ ctx,
+                                                            __bf16* __restrict__ ctx16) {
   constexpr int LD = DH + 1;   // tile pitch: conflict-free column reads
   constexpr int CF = DH / 32;  // 32-wide blocks of the head dimension
   __shared__ float Ta[64 * LD];  // Q block, later the V block
@@ -291,11 +298,15 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* __restr
     const uint32_t q = q0 + 32 * qf + c32;
     if (q >= L) continue;
     const float inv = 1.0f / lrun[qf];
-    float* op = ctx + ((uint64_t)b * L + q) * h + hd * DH;
+    const uint64_t obase = ((uint64_t)b * L + q) * h + hd * DH;
 #pragma unroll
     for (int cf = 0; cf < CF; ++cf)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) op[32 * cf + 8 * (r / 4) + 4 * kh + (r % 4)] = o[cf][qf][r] * inv;
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t c = 32 * cf + 8 * (r / 4) + 4 * kh + (r % 4);
+        if (ctx16) ctx16[obase + c] = (__bf16)(o[cf][qf][r] * inv);  // bf16 mode: only the next GEMM reads it
+        else ctx[obase + c] = o[cf][qf][r] * inv;
+      }
   }
 }
 
@@ -328,10 +339,11 @@ __global__ __launch_bounds__(64) void pool_kernel(const float* __restrict__ hid,
 isl_status ensure_ws(isl_encoder* e, uint64_t B, uint64_t L) {
   const uint64_t tokens = B * L;
   if (tokens <= e->ws_tokens) return ISL_OK;
-  void* olds[] = {e->x, e->x1, e->t, e->qkv, e->ctx, e->inter, e->d_mask, e->d_ids, e->d_tt};
+  void* olds[] = {e->x, e->x1, e->t, e->qkv, e->ctx, e->inter, e->d_mask, e->d_ids, e->d_tt, e->x16, e->x1_16};
   for (void* p : olds)
     if (p) (void)hipFree(p);
   e->x = e->x1 = e->t = e->qkv = e->ctx = e->inter = e->d_mask = nullptr;
+  e->x16 = e->x1_16 = nullptr;
   e->d_ids = e->d_tt = nullptr;
   e->ws_tokens = 0;
   const uint64_t h = e->cfg.hidden, I = e->cfg.intermediate;
@@ -339,7 +351,8 @@ isl_status ensure_ws(isl_encoder* e, uint64_t B, uint64_t L) {
       hipMalloc(&e->t, tokens * h * 4) != hipSuccess || hipMalloc(&e->qkv, tokens * 3 * h * 4) != hipSuccess ||
       hipMalloc(&e->ctx, tokens * h * 4) != hipSuccess || hipMalloc(&e->inter, tokens * I * 4) != hipSuccess ||
       hipMalloc(&e->d_mask, tokens * 4) != hipSuccess || hipMalloc(&e->d_ids, tokens * 8) != hipSuccess ||
-      hipMalloc(&e->d_tt, tokens * 8) != hipSuccess)
+      hipMalloc(&e->d_tt, tokens * 8) != hipSuccess || hipMalloc(&e->x16, tokens * h * 2) != hipSuccess ||
+      hipMalloc(&e->x1_16, tokens * h * 2) != hipSuccess)
     return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed for the encoder workspace (%llu tokens)",
                      (unsigned long long)tokens);
   e->ws_tokens = tokens;
@@ -357,35 +370,41 @@ isl_status compute_forward(isl_encoder* e, bool has_tt, uint64_t B, uint64_t L, 
   const isl_bert_config& c = e->cfg;
   const uint64_t M = B * L, h = c.hidden, I = c.intermediate;
   ISL_HIP(hipMemsetAsync(e->d_flag, 0, 4, st));
+  const uint32_t dh = c.hidden / c.heads;
+  static const bool valu_attention = getenv("ISL_ATTENTION_VALU") != nullptr;
+  // bf16 mode: every GEMM input is kept as a bf16 copy written by its producer (LayerNorm,
+  // attention, the GELU epilogue); ctx and inter only exist in bf16 then (in their f32 buffers)
+  const bool half = e->precision == ISL_DTYPE_BF16 && !e->layers16.empty() && h % 8 == 0 && I % 8 == 0 &&
+                    (dh == 64 || dh == 32) && !valu_attention;
+  __bf16* x16 = half ? reinterpret_cast<__bf16*>(e->x16) : nullptr;
+  __bf16* x1_16 = half ? reinterpret_cast<__bf16*>(e->x1_16) : nullptr;
+  __bf16* ctx16 = half ? reinterpret_cast<__bf16*>(e->ctx) : nullptr;
   hipLaunchKernelGGL(embed_ln_kernel, dim3((uint32_t)M), dim3(64), h * 4, st, e->d_ids,
                      has_tt ? e->d_tt : nullptr, (uint32_t)L, (uint32_t)h, c.vocab_size, c.type_vocab,
-                     e->word, e->pos, e->type, e->eln_w, e->eln_b, c.layer_norm_eps, e->x, e->d_flag);
-  const uint32_t dh = c.hidden / c.heads;
-  const bool half = e->precision == ISL_DTYPE_BF16 && !e->layers16.empty() && h % 8 == 0 && I % 8 == 0;
+                     e->word, e->pos, e->type, e->eln_w, e->eln_b, c.layer_norm_eps, e->x, e->d_flag, x16);
   for (size_t li = 0; li < e->layers.size(); ++li) {
     const auto& ly = e->layers[li];
-    if (half) launch_gemm_bf16<0, false>(e->x, (const __bf16*)e->layers16[li].wqkv, ly.bqkv, nullptr, e->qkv, M, 3 * h, h, st);
+    if (half) launch_gemm_bf16<0, false, true, false>(x16, (const __bf16*)e->layers16[li].wqkv, ly.bqkv, nullptr, e->qkv, M, 3 * h, h, st);
     else launch_gemm<0, false>(e->x, ly.wqkv, ly.bqkv, nullptr, e->qkv, M, 3 * h, h, st);
     dim3 ag((uint32_t)(B * c.heads), (uint32_t)((L + 63) / 64));
-    static const bool valu_attention = getenv("ISL_ATTENTION_VALU") != nullptr;
-    if (dh == 64 && !valu_attention) hipLaunchKernelGGL(attention_mfma_kernel<64>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
-    else if (dh == 32 && !valu_attention) hipLaunchKernelGGL(attention_mfma_kernel<32>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
+    if (dh == 64 && !valu_attention) hipLaunchKernelGGL(attention_mfma_kernel<64>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx, ctx16);
+    else if (dh == 32 && !valu_attention) hipLaunchKernelGGL(attention_mfma_kernel<32>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx, ctx16);
     else if (dh == 64) hipLaunchKernelGGL(attention_kernel<64>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
     else if (dh == 32) hipLaunchKernelGGL(attention_kernel<32>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
     else hipLaunchKernelGGL(attention_kernel<16>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
-    if (half) launch_gemm_bf16<0, true>(e->ctx, (const __bf16*)e->layers16[li].wo, ly.bo, e->x, e->t, M, h, h, st);
+    if (half) launch_gemm_bf16<0, true, true, false>(ctx16, (const __bf16*)e->layers16[li].wo, ly.bo, e->x, e->t, M, h, h, st);
     else launch_gemm<0, true>(e->ctx, ly.wo, ly.bo, e->x, e->t, M, h, h, st);
-    hipLaunchKernelGGL(ln_kernel, dim3((uint32_t)M), dim3(64), h * 4, st, e->t, (uint32_t)h, ly.ln1w, ly.ln1b, c.layer_norm_eps, e->x1);
+    hipLaunchKernelGGL(ln_kernel, dim3((uint32_t)M), dim3(64), h * 4, st, e->t, (uint32_t)h, ly.ln1w, ly.ln1b, c.layer_norm_eps, e->x1, x1_16);
     if (half) {
-      if (c.gelu_tanh) launch_gemm_bf16<2, false>(e->x1, (const __bf16*)e->layers16[li].wi, ly.bi, nullptr, e->inter, M, I, h, st);
-      else launch_gemm_bf16<1, false>(e->x1, (const __bf16*)e->layers16[li].wi, ly.bi, nullptr, e->inter, M, I, h, st);
-      launch_gemm_bf16<0, true>(e->inter, (const __bf16*)e->layers16[li].wo2, ly.bo2, e->x1, e->t, M, h, I, st);
+      if (c.gelu_tanh) launch_gemm_bf16<2, false, true, true>(x1_16, (const __bf16*)e->layers16[li].wi, ly.bi, nullptr, e->inter, M, I, h, st);
+      else launch_gemm_bf16<1, false, true, true>(x1_16, (const __bf16*)e->layers16[li].wi, ly.bi, nullptr, e->inter, M, I, h, st);
+      launch_gemm_bf16<0, true, true, false>(e->inter, (const __bf16*)e->layers16[li].wo2, ly.bo2, e->x1, e->t, M, h, I, st);
     } else {
       if (c.gelu_tanh) launch_gemm<2, false>(e->x1, ly.wi, ly.bi, nullptr, e->inter, M, I, h, st);
       else launch_gemm<1, false>(e->x1, ly.wi, ly.bi, nullptr, e->inter, M, I, h, st);
       launch_gemm<0, true>(e->inter, ly.wo2, ly.bo2, e->x1, e->t, M, h, I, st);
     }
-    hipLaunchKernelGGL(ln_kernel, dim3((uint32_t)M), dim3(64), h * 4, st, e->t, (uint32_t)h, ly.ln2w, ly.ln2b, c.layer_norm_eps, e->x);
+    hipLaunchKernelGGL(ln_kernel, dim3((uint32_t)M), dim3(64), h * 4, st, e->t, (uint32_t)h, ly.ln2w, ly.ln2b, c.layer_norm_eps, e->x, x16);
   }
   ISL_HIP(hipGetLastError());
   return ISL_OK;
@@ -464,7 +483,7 @@ void isl_encoder_free(isl_encoder* e) {
   if (e->device >= 0) {
     (void)hipSetDevice(e->device);
     for (void* p : e->owned) (void)hipFree(p);
-    void* ws[] = {e->x, e->x1, e->t, e->qkv, e->ctx, e->inter, e->d_mask, e->d_ids, e->d_tt, e->d_flag};
+    void* ws[] = {e->x, e->x1, e->t, e->qkv, e->ctx, e->inter, e->d_mask, e->d_ids, e->d_tt, e->d_flag, e->x16, e->x1_16};
     for (void* p : ws)
       if (p) (void)hipFree(p);
   }

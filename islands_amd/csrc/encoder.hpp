@@ -22,6 +22,7 @@ struct isl_encoder {
   // workspace, grown on demand (tokens = sequences * padded length)
   uint64_t ws_tokens = 0;
   float *x = nullptr, *x1 = nullptr, *t = nullptr, *qkv = nullptr, *ctx = nullptr, *inter = nullptr;
+  void *x16 = nullptr, *x1_16 = nullptr;  // bf16 copies of x / x1 (bf16 mode)
   float* d_mask = nullptr;
   int64_t *d_ids = nullptr, *d_tt = nullptr;
   uint32_t* d_flag = nullptr;

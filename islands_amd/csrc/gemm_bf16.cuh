@@ -18,12 +18,17 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int HBK = 64;          // k per slab
 constexpr int HLD = HBK + 8;     // LDS row pitch in bf16 (144 bytes: conflict-free 16-byte reads)
 
-template <int ACT, bool RES>
-__global__ __launch_bounds__(256) void gemm_tn_bf16(const float* __restrict__ A,
+// A16: A is already bf16 (activations kept in bf16 between the kernels); C16: C is written as bf16.
+template <int ACT, bool RES, bool A16, bool C16>
+__global__ __launch_bounds__(256) void gemm_tn_bf16(const void* __restrict__ Av,
                                                     const __bf16* __restrict__ W,
                                                     const float* __restrict__ bias,
-                                                    const float* __restrict__ R, float* __restrict__ C,
+                                                    const float* __restrict__ R, void* __restrict__ Cv,
                                                     uint32_t M, uint32_t N, uint32_t K) {
+  const float* A = reinterpret_cast<const float*>(Av);
+  const __bf16* Ah = reinterpret_cast<const __bf16*>(Av);
+  float* C = reinterpret_cast<float*>(Cv);
+  __bf16* Ch = reinterpret_cast<__bf16*>(Cv);
   __shared__ __attribute__((aligned(16))) __bf16 As[BM * HLD];
   __shared__ __attribute__((aligned(16))) __bf16 Bs[BN * HLD];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -38,18 +43,34 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const float* __restrict__ A,
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   // A slab: 128 rows x 64 floats = 2048 float4 -> 8 per thread (row = idx / 16, 4-float column
   // group = idx % 16); W slab: 128 rows x 64 bf16 = 1024 x 16 bytes -> 4 per thread (row = idx / 8)
-  float4 pa[8];
+  float4 pa[A16 ? 1 : 8];
+  bf16x8 pa16[A16 ? 4 : 1];
   bf16x8 pb[4];
   const bool edge = m0 + BM > M || n0 + BN > N || (K % HBK) != 0;
   auto fetch = [&](uint32_t k0) {
+    if constexpr (A16) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const uint32_t idx = tid + 256u * i, r = idx >> 4, c = (idx & 15) * 4;
-      const bool out = edge && (m0 + r >= M || k0 + c >= K);  // K is a multiple of 8 (host check)
-      const uint64_t rr = (m0 + r < M) ? m0 + r : (uint64_t)M - 1;
-      const uint32_t kc = (k0 + c < K) ? k0 + c : 0u;
-      pa[i] = *reinterpret_cast<const float4*>(A + rr * K + kc);
-      if (out) pa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t idx = tid + 256u * i, r = idx >> 3, c = (idx & 7) * 8;
+        const bool out = edge && (m0 + r >= M || k0 + c >= K);
+        const uint64_t rr = (m0 + r < M) ? m0 + r : (uint64_t)M - 1;
+        const uint32_t kc = (k0 + c < K) ? k0 + c : 0u;
+        pa16[i] = *reinterpret_cast<const bf16x8*>(Ah + rr * K + kc);
+        if (out) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pa16[i][e] = (__bf16)0.0f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t idx = tid + 256u * i, r = idx >> 4, c = (idx & 15) * 4;
+        const bool out = edge && (m0 + r >= M || k0 + c >= K);  // K is a multiple of 8 (host check)
+        const uint64_t rr = (m0 + r < M) ? m0 + r : (uint64_t)M - 1;
+        const uint32_t kc = (k0 + c < K) ? k0 + c : 0u;
+        pa[i] = *reinterpret_cast<const float4*>(A + rr * K + kc);
+        if (out) pa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -65,12 +86,20 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const float* __restrict__ A,
     }
   };
   auto stage = [&]() {
+    if constexpr (A16) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const uint32_t idx = tid + 256u * i, r = idx >> 4, c = (idx & 15) * 4;
-      bf16x4 v;
-      v[0] = (__bf16)pa[i].x; v[1] = (__bf16)pa[i].y; v[2] = (__bf16)pa[i].z; v[3] = (__bf16)pa[i].w;
-      *reinterpret_cast<bf16x4*>(&As[r * HLD + c]) = v;
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t idx = tid + 256u * i, r = idx >> 3, c = (idx & 7) * 8;
+        *reinterpret_cast<bf16x8*>(&As[r * HLD + c]) = pa16[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t idx = tid + 256u * i, r = idx >> 4, c = (idx & 15) * 4;
+        bf16x4 v;
+        v[0] = (__bf16)pa[i].x; v[1] = (__bf16)pa[i].y; v[2] = (__bf16)pa[i].z; v[3] = (__bf16)pa[i].w;
+        *reinterpret_cast<bf16x4*>(&As[r * HLD + c]) = v;
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -113,16 +142,17 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const float* __restrict__ A,
         if (ACT == 1) v = gelu_erf_f(v);
         if (ACT == 2) v = gelu_tanh_f(v);
         if (RES) v += R[m * N + n];
-        C[m * N + n] = v;
+        if constexpr (C16) Ch[m * N + n] = (__bf16)v;
+        else C[m * N + n] = v;
       }
     }
 }
 
-template <int ACT, bool RES>
-void launch_gemm_bf16(const float* A, const __bf16* W, const float* bias, const float* R, float* C,
+template <int ACT, bool RES, bool A16, bool C16>
+void launch_gemm_bf16(const void* A, const __bf16* W, const float* bias, const float* R, void* C,
                       uint64_t M, uint64_t N, uint64_t K, hipStream_t st) {
   dim3 grid((uint32_t)((N + BN - 1) / BN), (uint32_t)((M + BM - 1) / BM));
-  hipLaunchKernelGGL((gemm_tn_bf16<ACT, RES>), grid, dim3(256), 0, st, A, W, bias, R, C, (uint32_t)M,
+  hipLaunchKernelGGL((gemm_tn_bf16<ACT, RES, A16, C16>), grid, dim3(256), 0, st, A, W, bias, R, C, (uint32_t)M,
                      (uint32_t)N, (uint32_t)K);
 }
 
