@@ -19,7 +19,7 @@ constexpr int HBK = 64;          // k per slab
 constexpr int HLD = HBK + 8;     // LDS row pitch in bf16 (144 bytes: conflict-free 16-byte reads)
 
 // A16: A is already bf16 (activations kept in bf16 between the kernels); C16: C is written as bf16.
-template <int ACT, bool RES, bool A16, bool C16>
+template <int ACT, bool RES, bool A16, bool C16, int MF>
 __global__ __launch_bounds__(256) void gemm_tn_bf16(const void* __restrict__ Av,
                                                     const __bf16* __restrict__ W,
                                                     const float* __restrict__ bias,
@@ -29,28 +29,30 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const void* __restrict__ Av,
   const __bf16* Ah = reinterpret_cast<const __bf16*>(Av);
   float* C = reinterpret_cast<float*>(Cv);
   __bf16* Ch = reinterpret_cast<__bf16*>(Cv);
-  __shared__ __attribute__((aligned(16))) __bf16 As[BM * HLD];
+  constexpr int TM = 64 * MF;  // tile rows: every wave owns MF x 2 blocks of 32 x 32
+  __shared__ __attribute__((aligned(16))) __bf16 As[TM * HLD];
   __shared__ __attribute__((aligned(16))) __bf16 Bs[BN * HLD];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const uint64_t m0 = (uint64_t)blockIdx.y * BM, n0 = (uint64_t)blockIdx.x * BN;
-  floatx16 acc[2][2];
+  const uint32_t wm = (wave >> 1) * (32 * MF), wn = (wave & 1) * 64;
+  const uint64_t m0 = (uint64_t)blockIdx.y * TM, n0 = (uint64_t)blockIdx.x * BN;
+  floatx16 acc[MF][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MF; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   // A slab: 128 rows x 64 floats = 2048 float4 -> 8 per thread (row = idx / 16, 4-float column
   // group = idx % 16); W slab: 128 rows x 64 bf16 = 1024 x 16 bytes -> 4 per thread (row = idx / 8)
-  float4 pa[A16 ? 1 : 8];
-  bf16x8 pa16[A16 ? 4 : 1];
+  constexpr int NA32 = TM / 16, NA16 = TM / 32;  // loads per thread of an A slab (f32 / bf16)
+  float4 pa[A16 ? 1 : NA32];
+  bf16x8 pa16[A16 ? NA16 : 1];
   bf16x8 pb[4];
-  const bool edge = m0 + BM > M || n0 + BN > N || (K % HBK) != 0;
+  const bool edge = m0 + TM > M || n0 + BN > N || (K % HBK) != 0;
   auto fetch = [&](uint32_t k0) {
     if constexpr (A16) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NA16; ++i) {
         const uint32_t idx = tid + 256u * i, r = idx >> 3, c = (idx & 7) * 8;
         const bool out = edge && (m0 + r >= M || k0 + c >= K);
         const uint64_t rr = (m0 + r < M) ? m0 + r : (uint64_t)M - 1;
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const void* __restrict__ Av,
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < NA32; ++i) {
         const uint32_t idx = tid + 256u * i, r = idx >> 4, c = (idx & 15) * 4;
         const bool out = edge && (m0 + r >= M || k0 + c >= K);  // K is a multiple of 8 (host check)
         const uint64_t rr = (m0 + r < M) ? m0 + r : (uint64_t)M - 1;
@@ -88,13 +90,13 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const void* __restrict__ Av,
   auto stage = [&]() {
     if constexpr (A16) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NA16; ++i) {
         const uint32_t idx = tid + 256u * i, r = idx >> 3, c = (idx & 7) * 8;
         *reinterpret_cast<bf16x8*>(&As[r * HLD + c]) = pa16[i];
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < NA32; ++i) {
         const uint32_t idx = tid + 256u * i, r = idx >> 4, c = (idx & 15) * 4;
         bf16x4 v;
         v[0] = (__bf16)pa[i].x; v[1] = (__bf16)pa[i].y; v[2] = (__bf16)pa[i].z; v[3] = (__bf16)pa[i].w;
@@ -116,19 +118,19 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const void* __restrict__ Av,
 #pragma unroll
     for (int ks = 0; ks < HBK / 16; ++ks) {
       const uint32_t ko = 16 * ks + 8 * kh;
-      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&As[(wm + c32) * HLD + ko]);
-      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[(wm + 32 + c32) * HLD + ko]);
       const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&Bs[(wn + c32) * HLD + ko]);
       const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Bs[(wn + 32 + c32) * HLD + ko]);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MF; ++i) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(&As[(wm + 32 * i + c32) * HLD + ko]);
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[i][1], 0, 0, 0);
+      }
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MF; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const uint64_t n = n0 + wn + j * 32 + c32;
@@ -151,9 +153,11 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const void* __restrict__ Av,
 template <int ACT, bool RES, bool A16, bool C16>
 void launch_gemm_bf16(const void* A, const __bf16* W, const float* bias, const float* R, void* C,
                       uint64_t M, uint64_t N, uint64_t K, hipStream_t st) {
+  // MF = 4 (256-row tiles, 128 x 64 per wave: 6 LDS operand reads per 8 MFMAs instead of 4 per 4)
+  // was measured slower: 272 registers leave one wave per SIMD (27 ms against 18 ms end to end)
   dim3 grid((uint32_t)((N + BN - 1) / BN), (uint32_t)((M + BM - 1) / BM));
-  hipLaunchKernelGGL((gemm_tn_bf16<ACT, RES, A16, C16>), grid, dim3(256), 0, st, A, W, bias, R, C, (uint32_t)M,
-                     (uint32_t)N, (uint32_t)K);
+  hipLaunchKernelGGL((gemm_tn_bf16<ACT, RES, A16, C16, 2>), grid, dim3(256), 0, st, A, W, bias, R, C,
+                     (uint32_t)M, (uint32_t)N, (uint32_t)K);
 }
 
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, uint64_t n) {
