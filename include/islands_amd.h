@@ -392,6 +392,34 @@ isl_status isl_hnsw_search_batch(const isl_hnsw* h, const float* queries, uint64
  * exact_path = queries in which two equal distances met and the heap-exact kernel decided. */
 isl_status isl_hnsw_last_stats(const isl_hnsw* h, isl_search_stats* out);
 
+/* ---- EXTENSION: two-level search with a PQ filter ----
+ * "Algorithm 2: Two-Level Search with Hybrid Distance", docs/leann-specification.md:223-275; the
+ * reference promises it (leann.rs:54-56, :855-857: "a two-level search with PQ filtering should
+ * be used") and ships no implementation, so there is no reference result to be identical to.
+ * The rules the pseudo-code leaves open are fixed in oracle/islands_oracle.c
+ * (orc_two_level_search), which the device path matches bit for bit: every new neighbour gets
+ * ProductQuantizer::table_distance (pq.rs:341-348) on the tables of build_distance_tables
+ * (pq.rs:307-338); after each expansion the not yet promoted members of the first
+ * ceil(rerank_ratio * |AQ|) entries of the approximate queue get their exact distance from the
+ * index's embedding provider (in-memory or recompute) and enter the result set.
+ *
+ * isl_index_set_pq_codes: codes [n][pq->m] u16 as ProductQuantizer::encode writes them
+ * (pq.rs:221-244), copied to the device; `pq` is borrowed and must outlive the index.  A code
+ * >= num_centroids -> ISL_ERR_PQ (the reference's tables[sq][code] would panic). */
+isl_status isl_index_set_pq_codes(isl_index* idx, const isl_pq* pq, const uint16_t* codes, uint64_t n,
+                                  int32_t mem);
+/* Same outputs and error behaviour as isl_search_batch / isl_search_batch_device.
+ * isl_search_last_stats afterwards: evals = exact distance evaluations, pushes = approximate
+ * (table) evaluations.  ISL_ERR_SEARCH when ceil(rerank_ratio * |AQ|) outgrows the queue window a
+ * wave keeps in LDS (up to 16384 entries) -- never a different answer. */
+isl_status isl_search_two_level_batch(const isl_index* idx, const float* queries, uint64_t nq, uint64_t d,
+                                      uint64_t k, uint64_t ef, float rerank_ratio, uint64_t* out_ids,
+                                      float* out_dist, uint32_t* out_count);
+isl_status isl_search_two_level_batch_device(const isl_index* idx, const float* d_queries, uint64_t nq,
+                                             uint64_t d, uint64_t k, uint64_t ef, float rerank_ratio,
+                                             uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count,
+                                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -476,6 +476,47 @@ class LeannIndex:
                                            _ptr(cnt)))
         return ids[:, :k], dist[:, :k], cnt
 
+    # ---- extension: two-level search with a PQ filter (docs/leann-specification.md:223-275) ----
+    def set_pq_codes(self, pq: "ProductQuantizer", codes=None, device_ptr: int | None = None,
+                     n: int | None = None):
+        """Attach the quantizer (borrowed) and the code row of every node, [n][pq.m] u16 as
+        ProductQuantizer::encode returns them (pq.rs:221-244)."""
+        if device_ptr is not None:
+            _check(_ffi.lib().isl_index_set_pq_codes(self._h, pq._h, C.c_void_p(device_ptr), n,
+                                                     MEM_DEVICE))
+        else:
+            c = np.ascontiguousarray(codes, dtype=np.uint16)
+            if c.ndim != 2 or c.shape[1] != pq.m:
+                raise CoreError(10, "PQ error: codes must be [n][num_subquantizers]")
+            _check(_ffi.lib().isl_index_set_pq_codes(self._h, pq._h, _ptr(c), c.shape[0], MEM_HOST))
+        self._pq = pq  # keep the borrowed quantizer alive
+        return self
+
+    def search_two_level_batch(self, queries, k: int, ef: int, rerank_ratio: float, provider=None):
+        """Algorithm 2 of the reference's specification (not implemented there): PQ distances for
+        every new neighbour, exact distances for the top `rerank_ratio` of the approximate queue.
+        Same return values as search_batch."""
+        self._attach(provider)
+        q = _f32(queries)
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        nq, d = q.shape
+        ids = np.zeros((nq, max(k, 1)), dtype=np.uint64)
+        dist = np.zeros((nq, max(k, 1)), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        _check(_ffi.lib().isl_search_two_level_batch(self._h, _ptr(q), nq, d, k, ef,
+                                                     C.c_float(rerank_ratio), _ptr(ids), _ptr(dist),
+                                                     _ptr(cnt)))
+        return ids[:, :k], dist[:, :k], cnt
+
+    def search_two_level_batch_device(self, d_queries_ptr: int, nq: int, d: int, k: int, ef: int,
+                                      rerank_ratio: float, d_ids_ptr: int, d_dist_ptr: int,
+                                      d_count_ptr: int, stream: int = 0):
+        _check(_ffi.lib().isl_search_two_level_batch_device(
+            self._h, C.c_void_p(d_queries_ptr), nq, d, k, ef, C.c_float(rerank_ratio),
+            C.c_void_p(d_ids_ptr), C.c_void_p(d_dist_ptr), C.c_void_p(d_count_ptr),
+            C.c_void_p(stream)))
+
     def search_batch_device(self, d_queries_ptr: int, nq: int, d: int, k: int, ef: int,
                             d_ids_ptr: int, d_dist_ptr: int, d_count_ptr: int, stream: int = 0):
         _check(_ffi.lib().isl_search_batch_device(

@@ -93,6 +93,7 @@ void free_workspace(SearchWorkspace& ws) {
   if (ws.miss) (void)hipFree(ws.miss);
   if (ws.uniq) (void)hipFree(ws.uniq);
   if (ws.uniq_count) (void)hipFree(ws.uniq_count);
+  if (ws.tl_tables) (void)hipFree(ws.tl_tables);
   if (ws.ev0) (void)hipEventDestroy(ws.ev0);
   if (ws.ev1) (void)hipEventDestroy(ws.ev1);
   if (ws.ev_in) (void)hipEventDestroy(ws.ev_in);
@@ -282,6 +283,7 @@ void isl_index_free(isl_index* idx) {
     if (idx->d_adj) (void)hipFree(idx->d_adj);
     if (idx->d_emb) (void)hipFree(idx->d_emb);
     if (idx->d_norm2) (void)hipFree(idx->d_norm2);
+    if (idx->d_codes) (void)hipFree(idx->d_codes);
     for (void* q : idx->hnsw_owned) (void)hipFree(q);
     if (idx->d_layer_off) (void)hipFree((void*)idx->d_layer_off);
     if (idx->d_layer_adj) (void)hipFree((void*)idx->d_layer_adj);

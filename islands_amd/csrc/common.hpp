@@ -95,11 +95,22 @@ struct SearchWorkspace {
   uint32_t* uniq = nullptr;
   uint32_t* uniq_count = nullptr;
   uint64_t miss_cap = 0;
+  // two-level search: per-query PQ distance tables [nq][m * K]
+  float* tl_tables = nullptr;
+  uint64_t tl_tables_cap = 0;
 };
 
 constexpr int kSearchLanes = 16;  // independent workspaces = searches that may be in flight
 
 }  // namespace isl
+
+// ProductQuantizer (pq.rs:109-118) resident on a device: the codebooks.
+struct isl_pq {
+  uint64_t dimension = 0, m = 0, K = 0, dsub = 0, cstride = 0;
+  int32_t metric = ISL_METRIC_EUCLIDEAN;
+  int32_t device = 0;
+  float* d_codebooks = nullptr;  // [m][K][cstride], rows 16-byte aligned, slack at the end
+};
 
 // The opaque handle of the ABI.  Host side mirrors LeannIndex (leann.rs:492-500).
 struct isl_index {
@@ -154,6 +165,12 @@ struct isl_index {
   const uint32_t** d_layer_adj = nullptr;
   std::vector<void*> hnsw_owned;           // device allocations of the upper layers
 
+  // two-level search (extension): PQ codes of every node, [ncodes][pq->m] u16 as ProductQuantizer::encode
+  // writes them (pq.rs:221-244); the quantizer is borrowed
+  const isl_pq* pq = nullptr;
+  uint16_t* d_codes = nullptr;
+  uint64_t ncodes = 0;
+
   mutable std::mutex mu;  // serialises searches that share the workspace
   mutable isl::SearchWorkspace ws[isl::kSearchLanes];
   mutable uint64_t next_token = 1;
@@ -167,5 +184,8 @@ isl_status search_device_sync(const isl_index* idx, const float* d_queries, uint
                               uint64_t k, uint64_t ef, uint64_t* d_ids, float* d_dist,
                               uint32_t* d_count, hipStream_t stream);
 isl_status materialise_host_csr(const isl_index* idx);
+// build_distance_tables (pq.rs:307-338) for nq device-resident queries into d_tables [nq][m][K]
+isl_status pq_launch_tables(const isl_pq* pq, const float* d_queries, uint64_t nq, float* d_tables,
+                            hipStream_t st);
 void free_workspace(SearchWorkspace& ws);
 }  // namespace isl

@@ -7,13 +7,6 @@
 #include <algorithm>
 #include <cfloat>
 
-struct isl_pq {
-  uint64_t dimension = 0, m = 0, K = 0, dsub = 0, cstride = 0;
-  int32_t metric = ISL_METRIC_EUCLIDEAN;
-  int32_t device = 0;
-  float* d_codebooks = nullptr;  // [m][K][cstride], rows 16-byte aligned, slack at the end
-};
-
 namespace {
 
 using namespace isl_dev;
@@ -129,6 +122,13 @@ isl_status launch_tables(const isl_pq* pq, const float* d_queries, uint64_t nq, 
 }
 
 }  // namespace
+
+namespace isl {
+isl_status pq_launch_tables(const isl_pq* pq, const float* d_queries, uint64_t nq, float* d_tables,
+                            hipStream_t st) {
+  return launch_tables(pq, d_queries, nq, d_tables, st);
+}
+}  // namespace isl
 
 extern "C" {
 

@@ -102,6 +102,13 @@ struct SearchParams {
   uint32_t seq_max;     // hops with at most this many pushes insert one by one (cheaper than a merge)
   uint32_t* q_entry;    // [nq] layer-0 entry per query after the greedy descent (HnswGraph), or NULL
   uint32_t* q_evals;    // [nq] distance evaluations of the descent (+ 1 for the entry point)
+  // two-level search (extension, leann_search_two_level)
+  const float* tl_tables;     // [nq][tl_m][tl_K] distances of build_distance_tables
+  const uint16_t* tl_codes;   // [tl_ncodes][tl_m]
+  uint64_t tl_ncodes;
+  uint32_t tl_m, tl_K;
+  float tl_ratio;
+  uint32_t tl_wcap;           // entries of the approximate queue kept in LDS (multiple of 64)
 };
 
 // ------------------------------------------------------------- sorted result set
@@ -1070,6 +1077,276 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
   }
 }
 
+
+// ----------------------------------------------------------- two-level search (EXTENSION)
+// "Algorithm 2: Two-Level Search with Hybrid Distance" of docs/leann-specification.md:223-275,
+// which the reference promises (leann.rs:54-56, :855-857) and does not implement.  The rules
+// the pseudo-code leaves open are fixed in oracle/islands_oracle.c (orc_two_level_search), the
+// definition this kernel is tested against:
+//   * R (<= ef exact results) and AQ (every node that got a PQ distance) are ascending arrays of
+//     64-bit keys in LDS: (ordkey(distance) << 32) | (id << 1) | flag, flag = expanded (R) or
+//     promoted (AQ).  EQ is implicit: the unexpanded members of R.
+//   * per hop: the new neighbours get table_distance (pq.rs:341-348, left fold over the
+//     subquantizers, one lane per neighbour) and are merged into AQ; the unpromoted members of
+//     the first ceil(a * |AQ|) entries get their exact distance and are merged into R.
+//   * only the smallest tl_wcap entries of AQ are kept: an entry that drops out is larger than
+//     tl_wcap others for good, so it can only matter when ceil(a * |AQ|) outgrows the window --
+//     then the query fails (QS_SCRATCH), it is never answered differently.
+__device__ __forceinline__ uint64_t rl_u64(uint64_t v, int lane) {
+  return ((uint64_t)rl_u((uint32_t)(v >> 32), lane) << 32) | (uint64_t)rl_u((uint32_t)v, lane);
+}
+
+// Merges the keys held by lanes [0, cnt) into the ascending array arr[0, len) in place (room for
+// len + 64); returns len + cnt.  Keys are pairwise different above bit 0.
+__device__ uint32_t tl_merge(uint64_t* arr, uint32_t len, uint64_t nk, uint32_t cnt, uint64_t* nbuf) {
+  const uint32_t lane = threadIdx.x;
+  const bool active = lane < cnt;
+  uint32_t rank = 0;
+  for (uint32_t j = 0; j < cnt; ++j) rank += rl_u64(nk, (int)j) < nk ? 1u : 0u;
+  uint32_t lo = 0, hi = active ? len : 0u;  // old entries below this lane's key
+  while (ballot(lo < hi)) {
+    const uint32_t mid = (lo + hi) >> 1;
+    const bool go = lo < hi;
+    const uint64_t v = go ? arr[mid] : 0ull;
+    if (go) { if (v < nk) lo = mid + 1; else hi = mid; }
+  }
+  if (active) nbuf[rank] = nk;
+  wave_sync();
+  // old entries move up by the number of new keys below them, last chunk first: a chunk is read
+  // whole before any of it is written, and writes never reach below the chunk being moved
+  uint32_t t = cnt;  // new keys not yet known to lie above everything still to be moved
+  for (int c = len ? (int)((len - 1) & ~63u) : -1; c >= 0 && t > 0; c -= 64) {
+    const uint32_t i = (uint32_t)c + lane;
+    const uint64_t x = i < len ? arr[i] : ~0ull;
+    const uint64_t first = rl_u64(x, 0);
+    uint32_t sh = t, tt = t;
+    while (tt > 0) {
+      const uint64_t kb = nbuf[tt - 1];
+      if (kb < first) break;
+      sh -= kb > x ? 1u : 0u;
+      tt -= 1;
+    }
+    wave_sync();
+    if (i < len && sh > 0) arr[i + sh] = x;
+    wave_sync();
+    t = tt;
+  }
+  if (active) arr[lo + rank] = nk;
+  wave_sync();
+  return len + cnt;
+}
+
+template <int METRIC_API, typename ROWT>
+__global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
+  constexpr int METRIC = METRIC_API == ISL_METRIC_COSINE ? METRIC_COSINE_PRE : METRIC_API;
+  const ROWT* const emb = reinterpret_cast<const ROWT*>(p.emb);
+  extern __shared__ __align__(16) unsigned char smem[];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t hcap = 1u << p.hbits;
+  const uint32_t hmask = hcap - 1;
+  const uint32_t hlimit = hcap - hcap / 8;
+  const uint32_t ef = p.ef;
+  const uint32_t wcap = p.tl_wcap;
+  uint32_t* htab = reinterpret_cast<uint32_t*>(smem);
+  uint64_t* win = reinterpret_cast<uint64_t*>(htab + hcap);  // hcap * 4 is a multiple of 8
+  uint64_t* res = win + (wcap + 64);
+  uint64_t* nbuf = res + ((ef + 63) / 64 * 64 + 64);
+  uint32_t* scratch = reinterpret_cast<uint32_t*>(nbuf + 64);
+  float* qs = reinterpret_cast<float*>(scratch + 64);
+  const uint32_t ocap = 1u << p.obits;
+  const uint32_t omask = ocap - 1;
+  const uint32_t olimit = ocap - ocap / 4;
+  uint32_t* otab = p.otab + (size_t)blockIdx.x * ocap;
+  const uint32_t m = p.tl_m, K = p.tl_K;
+
+  for (;;) {
+    uint32_t qi = 0;
+    if (lane == 0) qi = atomicAdd(&p.ticket[0], 1u);
+    qi = uni(qi);
+    if (qi >= p.nq) break;
+
+    for (uint32_t i = lane; i < hcap; i += 64) htab[i] = EMPTY;
+    const float q_norm = load_query<METRIC>(p.queries + (uint64_t)qi * p.d, p.d, qs);  // syncs
+    const float* tables = p.tl_tables + (uint64_t)qi * m * K;
+
+    uint32_t rlen = 0, wlen = 0, aq_total = 0;
+    uint32_t hcount = 0, ocount = 0;
+    bool ovf = false;
+    uint32_t status = QS_OK;
+    uint64_t payload = 0;
+    uint32_t cH = 0, cE = 0, cV = 0, cP = 0;
+
+    if ((uint64_t)p.entry >= p.nvec) {  // provider.compute_embedding(entry), leann.rs:911
+      status = QS_NODE_NOT_FOUND;
+      payload = p.entry;
+    } else if (!rows_present(p, p.entry, 1)) {
+      status = QS_BLOCKED;
+    } else {
+      const uint32_t entry = p.entry;
+      const float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[entry] : 0.0f;
+      float ed = direct_distances<METRIC, ROWT>(emb, p.stride, p.d, entry, 1, qs, q_norm, e_aux);
+      ed = rl_f(ed, 0);
+      cV = 1;
+      if (lane == 0) {
+        htab[hslot(entry, p.hbits)] = entry;
+        res[0] = ((uint64_t)ordkey(ed) << 32) | ((uint64_t)entry << 1);
+      }
+      hcount = 1;
+      rlen = 1;
+      wave_sync();
+    }
+
+    while (status == QS_OK) {
+      // extract_min(EQ): the first unexpanded member of R; none left -> done (lines 5-9)
+      uint32_t e = 0xFFFFFFFFu;
+      for (uint32_t c = 0; c < rlen; c += 64) {
+        const uint32_t i = c + lane;
+        const uint64_t x = i < rlen ? res[i] : ~0ull;
+        const uint64_t um = ballot(i < rlen && !(x & 1ull));
+        if (um) { e = c + (uint32_t)__ffsll((long long)um) - 1u; break; }
+      }
+      if (e == 0xFFFFFFFFu) break;
+      const uint64_t ekey = res[e];
+      wave_sync();
+      if (lane == 0) res[e] = ekey | 1ull;
+      wave_sync();
+      const uint32_t cid = (uint32_t)(ekey >> 1) & ID_MASK;
+      if ((uint64_t)cid >= p.num_nodes) continue;  // get_neighbors -> None, leann.rs:227-229
+      uint64_t o0;
+      uint32_t deg;
+      if (p.ell_w) { o0 = (uint64_t)cid * p.ell_w; deg = p.ell_deg[cid]; }
+      else { o0 = p.off[cid]; deg = (uint32_t)(p.off[cid + 1] - o0); }
+      cH += 1;
+      cE += deg;
+
+      // Phase 1 (lines 12-16): approximate distances of the unvisited neighbours, 64 at a time
+      for (uint32_t base = 0; base < deg && status == QS_OK; base += 64) {
+        const bool active = base + lane < deg;
+        const uint32_t nid = active ? p.adj[o0 + base + lane] : EMPTY;
+        const uint32_t batch = deg - base < 64 ? deg - base : 64;
+        if (!ovf && hcount + batch > hlimit) ovf = true;
+        bool is_new = false;
+        if (active) {
+          uint32_t h = hslot(nid, p.hbits);
+          if (!ovf) {
+            for (;;) {
+              uint32_t old = atomicCAS(&htab[h], EMPTY, nid);
+              if (old == EMPTY) { is_new = true; break; }
+              if (old == nid) break;
+              h = (h + 1) & hmask;
+            }
+          } else {
+            bool found = false;
+            for (;;) {
+              uint32_t cur = htab[h];
+              if (cur == nid) { found = true; break; }
+              if (cur == EMPTY) break;
+              h = (h + 1) & hmask;
+            }
+            if (!found) {
+              uint32_t g = hslot(nid, p.obits);
+              for (;;) {
+                uint32_t old = atomicCAS(&otab[g], EMPTY, nid);
+                if (old == EMPTY) { is_new = true; break; }
+                if (old == nid) break;
+                g = (g + 1) & omask;
+              }
+            }
+          }
+        }
+        const uint64_t nm = ballot(is_new);
+        const uint32_t nu = (uint32_t)__popcll(nm);
+        if (!ovf) hcount += nu;
+        else {
+          ocount += nu;
+          if (ocount > olimit) { status = QS_SCRATCH; payload = 2; break; }
+        }
+        if (nu == 0) continue;
+        const uint32_t rank = (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
+        if (is_new) scratch[rank] = nid;
+        wave_sync();
+        const uint32_t uid = lane < nu ? scratch[lane] : 0u;
+        wave_sync();
+        const uint64_t bad = ballot(lane < nu && (uint64_t)uid >= p.tl_ncodes);
+        if (bad) {
+          status = QS_NODE_NOT_FOUND;
+          payload = rl_u(uid, __ffsll((long long)bad) - 1);
+          break;
+        }
+        float s = 0.0f;
+        if (lane < nu) {
+          const uint16_t* cr = p.tl_codes + (uint64_t)uid * m;
+          for (uint32_t j = 0; j < m; ++j) s += tables[(uint64_t)j * K + cr[j]];
+        }
+        const float ad = sqrtf(s);
+        const uint64_t key = ((uint64_t)ordkey(ad) << 32) | ((uint64_t)uid << 1);
+        cP += nu;
+        aq_total += nu;
+        wlen = tl_merge(win, wlen, key, nu, nbuf);
+        if (wlen > wcap) wlen = wcap;
+      }
+      if (status != QS_OK || aq_total == 0) continue;
+
+      // Phase 2 (lines 19-27): M = the first ceil(a * |AQ|) entries of AQ, at least one
+      const float tf = ceilf(p.tl_ratio * (float)aq_total);
+      uint32_t ntop = tf >= 1.0f ? (tf >= (float)aq_total ? aq_total : (uint32_t)tf) : 1u;
+      if (ntop > aq_total) ntop = aq_total;
+      if (ntop > wlen) { status = QS_SCRATCH; payload = 7; break; }
+      for (uint32_t c = 0; c < ntop && status == QS_OK; c += 64) {
+        const uint32_t i = c + lane;
+        const uint64_t x = i < ntop ? win[i] : ~0ull;
+        const bool un = i < ntop && !(x & 1ull);
+        const uint64_t um = ballot(un);
+        const uint32_t pc = (uint32_t)__popcll(um);
+        if (!pc) continue;
+        const uint32_t rank = (uint32_t)__popcll(um & ((1ull << lane) - 1ull));
+        if (un) {
+          win[i] = x | 1ull;
+          scratch[rank] = (uint32_t)(x >> 1) & ID_MASK;
+        }
+        wave_sync();
+        const uint32_t pid = lane < pc ? scratch[lane] : 0u;
+        wave_sync();
+        const uint64_t bad = ballot(lane < pc && (uint64_t)pid >= p.nvec);
+        if (bad) {
+          status = QS_NODE_NOT_FOUND;
+          payload = rl_u(pid, __ffsll((long long)bad) - 1);
+          break;
+        }
+        if (!rows_present(p, pid, pc)) { status = QS_BLOCKED; break; }
+        cV += pc;
+        const float r_aux = (METRIC == METRIC_COSINE_PRE && lane < pc) ? p.norm2[pid] : 0.0f;
+        const float nd = direct_distances<METRIC, ROWT>(emb, p.stride, p.d, pid, pc, qs, q_norm, r_aux);
+        const uint64_t rkey = ((uint64_t)ordkey(nd) << 32) | ((uint64_t)pid << 1);
+        rlen = tl_merge(res, rlen, rkey, pc, nbuf);
+        if (rlen > ef) rlen = ef;  // line 26-27
+      }
+    }
+
+    const uint32_t outn = rlen < p.k ? rlen : p.k;
+    if (status == QS_OK) {
+      for (uint32_t e = lane; e < outn; e += 64) {
+        const uint64_t x = res[e];
+        p.out_ids[(uint64_t)qi * p.k + e] = (uint64_t)((uint32_t)(x >> 1) & ID_MASK);
+        p.out_dist[(uint64_t)qi * p.k + e] = key_to_dist((uint32_t)(x >> 32));
+      }
+    }
+    if (lane == 0) {
+      p.status[qi] = status;
+      p.payload[qi] = payload;
+      p.out_count[qi] = status == QS_OK ? outn : 0u;
+      p.ctr[qi * 4 + 0] = cH;
+      p.ctr[qi * 4 + 1] = cE;
+      p.ctr[qi * 4 + 2] = cV;
+      p.ctr[qi * 4 + 3] = cP;
+    }
+    if (ovf) {
+      for (uint32_t i = lane; i < ocap; i += 64) otab[i] = EMPTY;
+    }
+    wave_sync();
+  }
+}
+
 // ------------------------------------------------------------------ launchers
 struct FastGeom {
   uint32_t hbits;
@@ -1139,6 +1416,29 @@ void launch_exact(int metric, bool hnsw, uint32_t grid, size_t lds, hipStream_t 
                   const SearchParams& p) {
   if (hnsw) launch_exact_t<true>(metric, grid, lds, st, p);
   else launch_exact_t<false>(metric, grid, lds, st, p);
+}
+
+template <typename ROWT>
+void launch_two_level_t(int metric, uint32_t grid, size_t lds, hipStream_t st, const SearchParams& p) {
+  switch (metric) {
+    case ISL_METRIC_COSINE: launch_one(leann_search_two_level<ISL_METRIC_COSINE, ROWT>, grid, lds, st, p); break;
+    case ISL_METRIC_EUCLIDEAN: launch_one(leann_search_two_level<ISL_METRIC_EUCLIDEAN, ROWT>, grid, lds, st, p); break;
+    case ISL_METRIC_DOT: launch_one(leann_search_two_level<ISL_METRIC_DOT, ROWT>, grid, lds, st, p); break;
+    default: launch_one(leann_search_two_level<ISL_METRIC_MANHATTAN, ROWT>, grid, lds, st, p); break;
+  }
+}
+void launch_two_level(int metric, uint32_t grid, size_t lds, hipStream_t st, const SearchParams& p) {
+  if (p.emb_bf16) launch_two_level_t<uint16_t>(metric, grid, lds, st, p);
+  else launch_two_level_t<float>(metric, grid, lds, st, p);
+}
+
+// Two-level search: LDS of one wave = visited table + approximate-queue window + R + staging + query
+struct TwoLevelCall {
+  float ratio;
+};
+size_t two_level_lds(uint32_t hbits, uint32_t wcap, uint32_t ef, uint32_t d) {
+  return ((size_t)4 << hbits) + (size_t)(wcap + 64) * 8 + (size_t)((ef + 63) / 64 * 64 + 64) * 8 + 64 * 8 +
+         64 * 4 + (size_t)((d + 3) / 4 * 4) * 4 + ((d & 15) ? 64 : 0);
 }
 
 __global__ void fill_u32_kernel(uint32_t* p, uint64_t n, uint32_t v) {
@@ -1266,7 +1566,7 @@ enum class StreamMode { OWN, USER, OWN_AFTER_USER };
 isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const float* d_queries,
                           uint64_t nq, uint64_t d, uint64_t k, uint64_t ef_in, uint64_t* d_ids,
                           float* d_dist, uint32_t* d_count, hipStream_t user_stream,
-                          StreamMode mode) {
+                          StreamMode mode, const TwoLevelCall* tl = nullptr) {
   const uint32_t ef = (uint32_t)std::max(ef_in, k);  // leann.rs:890
   if (ef > kMaxExactEf)
     return isl::fail(ISL_ERR_UNSUPPORTED, "ef = %u exceeds the device limit %u", ef, kMaxExactEf);
@@ -1284,6 +1584,23 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   }();
   uint32_t per_cu = (uint32_t)std::min<size_t>(cu_cap, (160 * 1024) / fg.lds);
   if (per_cu == 0) use_fast = false;
+  uint32_t tl_wcap = 0;
+  size_t tl_lds = 0;
+  if (tl) {
+    // window of the approximate queue: ceil(a * |AQ|) must stay inside it; |AQ| is bounded by the
+    // node count and, in practice, by a few dozen times ef
+    use_fast = false;
+    const float a = tl->ratio > 0.0f ? std::min(tl->ratio, 1.0f) : 0.0f;
+    const double bound = (double)std::min<uint64_t>(idx->ncodes, (uint64_t)128 * ef);
+    const uint64_t want = (uint64_t)(a * bound) + 64;
+    tl_wcap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((want + 63) / 64 * 64, 256), 16384);
+    while (tl_wcap > 256 && two_level_lds(fg.hbits, tl_wcap, ef, (uint32_t)d) > 160 * 1024) tl_wcap -= 64;
+    tl_lds = two_level_lds(fg.hbits, tl_wcap, ef, (uint32_t)d);
+    if (tl_lds > 160 * 1024)
+      return isl::fail(ISL_ERR_UNSUPPORTED, "two-level search: ef = %u, d = %llu do not fit the LDS", ef,
+                       (unsigned long long)d);
+    per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(cu_cap, (160 * 1024) / tl_lds));
+  }
   uint32_t slots = std::max<uint32_t>(1, (uint32_t)ncu * std::max<uint32_t>(per_cu, 1));
   const uint32_t plog_cap = std::max<uint32_t>(1024, 12 * ef);  // pushes per query ~ 3-6 x ef
   // per-slot state is indexed by blockIdx.x < min(nq, slots)
@@ -1295,7 +1612,7 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
     ISL_HIP(hipStreamWaitEvent(ws.stream, ws.ev_in, 0));
   }
 
-  if (use_fast && !idx->d_ell && idx->d_off && idx->num_nodes) {
+  if ((use_fast || (tl && idx->max_degree <= 64)) && !idx->d_ell && idx->d_off && idx->num_nodes) {
     // padded copy of the adjacency (64 ids per node + a degree array): 260 bytes per node buy the
     // traversal one dependent memory round trip per hop
     isl_index* mi = const_cast<isl_index*>(idx);
@@ -1373,9 +1690,28 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   p.q_evals = nullptr;
   static const uint32_t seq_max_env = [] { const char* e = getenv("ISL_SEQ_MAX"); return e ? (uint32_t)atoi(e) : 0u; }();
   p.seq_max = seq_max_env;
+  if (tl) {
+    const isl_pq* pq = idx->pq;
+    const uint64_t want = nq * pq->m * pq->K;
+    ISL_TRY(ensure(ws.tl_tables, ws.tl_tables_cap, want));
+    p.tl_tables = ws.tl_tables;
+    p.tl_codes = idx->d_codes;
+    p.tl_ncodes = idx->ncodes;
+    p.tl_m = (uint32_t)pq->m;
+    p.tl_K = (uint32_t)pq->K;
+    p.tl_ratio = tl->ratio;
+    p.tl_wcap = tl_wcap;
+  }
 
   ISL_HIP(hipMemsetAsync(ws.ticket, 0, 64, st));
   ISL_HIP(hipEventRecord(ws.ev0, st));
+  if (tl) {
+    // build_distance_tables for the whole batch (pq.rs:307-338), then one wave per query
+    ISL_TRY(isl::pq_launch_tables(idx->pq, d_queries, nq, ws.tl_tables, st));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, slots);
+    launch_two_level((int)idx->cfg.metric, grid, tl_lds, st, p);
+    ISL_HIP(hipGetLastError());
+  } else
   if (use_fast && idx->is_hnsw && p.max_level > 0) {
     // HnswGraph::search: greedy descent through the upper layers first (its own kernel, so that
     // the traversal kernel keeps its register budget)
@@ -1398,7 +1734,8 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
     }
     ISL_HIP(hipGetLastError());
   }
-  if (use_fast) {
+  if (tl) {
+  } else if (use_fast) {
     uint32_t grid = (uint32_t)std::min<uint64_t>(nq, slots);
     int S = ef <= 64 ? 1 : ef <= 128 ? 2 : ef <= 256 ? 4 : 8;
     const int metric = (int)idx->cfg.metric;
@@ -1418,7 +1755,7 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
     ISL_HIP(hipMemcpyAsync(ws.ticket, head0, 16, hipMemcpyHostToDevice, st));
     ISL_HIP(hipStreamSynchronize(st));
   }
-  {
+  if (!tl) {
     uint32_t grid = (uint32_t)std::min<uint64_t>(nq, ws.exact_slots);
     launch_exact((int)idx->cfg.metric, idx->is_hnsw, grid, exact_lds(ef, (uint32_t)d), st, p);
     ISL_HIP(hipGetLastError());
@@ -1511,7 +1848,8 @@ isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws, uint32_
       return isl::fail_node(node);
     }
     if (status[i] == QS_SCRATCH)
-      return isl::fail(ISL_ERR_SEARCH, "Search error: candidate scratch exhausted for query %llu",
+      return isl::fail(ISL_ERR_SEARCH, "Search error: device scratch exhausted for query %llu (candidate heap, "
+                       "visited table or the two-level search's approximate-queue window)",
                        (unsigned long long)i);
     return isl::fail(ISL_ERR_SEARCH, "Search error: query %llu left in state 0x%x",
                      (unsigned long long)i, status[i]);
@@ -1554,9 +1892,10 @@ __global__ __launch_bounds__(64) void row_norm2_list_kernel(const float* __restr
 // round costs traversal time only, which is noise next to the encoder (5.5 GFLOP per node).
 isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const float* d_queries,
                        uint64_t nq, uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_ids,
-                       float* d_dist, uint32_t* d_count, hipStream_t user_stream, StreamMode mode) {
+                       float* d_dist, uint32_t* d_count, hipStream_t user_stream, StreamMode mode,
+                       const TwoLevelCall* tl = nullptr) {
   if (!idx->recompute) {
-    ISL_TRY(search_enqueue(idx, ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, user_stream, mode));
+    ISL_TRY(search_enqueue(idx, ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, user_stream, mode, tl));
     return search_finish(idx, ws);
   }
   const uint64_t cap = std::min<uint64_t>(nq * 64 + 64, 0xFFFFFFF0ull);
@@ -1576,7 +1915,7 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
   uint64_t encoded = 0, rounds = 0;
   double kernel_ms = 0.0;
   for (;;) {
-    ISL_TRY(search_enqueue(idx, ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, user_stream, mode));
+    ISL_TRY(search_enqueue(idx, ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, user_stream, mode, tl));
     uint32_t misses = 0;
     ISL_TRY(search_finish(idx, ws, &misses));
     kernel_ms += idx->stats.kernel_ms;
@@ -1636,6 +1975,23 @@ isl_status precheck(const isl_index* idx, uint64_t nq, uint64_t d, uint64_t k, u
     *done = 2;  // nothing to write but counts
   }
   return ISL_OK;
+}
+
+isl_status precheck_two_level(const isl_index* idx, uint64_t d) {
+  if (!idx->pq || !idx->d_codes)
+    return isl::fail(ISL_ERR_PQ, "PQ error: no PQ codes attached (isl_index_set_pq_codes)");
+  if (idx->is_hnsw) return isl::fail(ISL_ERR_UNSUPPORTED, "two-level search runs on a LeannIndex");
+  if (d != idx->pq->dimension) return isl::fail_dim(idx->pq->dimension, d);  // pq.rs:308-313
+  return ISL_OK;
+}
+
+__global__ void check_codes_kernel(const uint16_t* __restrict__ codes, uint64_t n, uint32_t K,
+                                   uint32_t* __restrict__ flag) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (; i < n; i += stride) bad |= codes[i] >= K;
+  if (bad) atomicOr(flag, 1u);
 }
 
 }  // namespace
@@ -1702,12 +2058,14 @@ isl_status isl_search_wait(const isl_index* idx, uint64_t token) {
   return isl::fail(ISL_ERR_INVALID_ARGUMENT, "unknown or already completed search token");
 }
 
-isl_status isl_search_batch(const isl_index* idx, const float* queries, uint64_t nq, uint64_t d,
-                            uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dist,
-                            uint32_t* out_count) {
+// host-pointer entry: stage the queries, search on the lane's stream, copy the answers back
+static isl_status search_batch_host(const isl_index* idx, const float* queries, uint64_t nq, uint64_t d,
+                                    uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dist,
+                                    uint32_t* out_count, const TwoLevelCall* tl) {
   int done = 0;
   ISL_TRY(precheck(idx, nq, d, k, out_count, false, &done));
   if (done == 1) return ISL_OK;
+  if (tl) ISL_TRY(precheck_two_level(idx, d));
   if (!queries || !out_count || (k && (!out_ids || !out_dist)))
     return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
   ISL_TRY(isl::use_device(idx->device));
@@ -1737,13 +2095,82 @@ isl_status isl_search_batch(const isl_index* idx, const float* queries, uint64_t
   }
   ISL_HIP(hipMemcpy(ws.q_stage, queries, qbytes, hipMemcpyHostToDevice));
   ISL_TRY(search_sync(idx, ws, ws.q_stage, nq, d, k, ef, ws.ids_stage, ws.dist_stage, ws.count_stage,
-                      nullptr, StreamMode::OWN));
+                      nullptr, StreamMode::OWN, tl));
   if (k) {
     ISL_HIP(hipMemcpy(out_ids, ws.ids_stage, nq * k * 8, hipMemcpyDeviceToHost));
     ISL_HIP(hipMemcpy(out_dist, ws.dist_stage, nq * k * 4, hipMemcpyDeviceToHost));
   }
   ISL_HIP(hipMemcpy(out_count, ws.count_stage, nq * 4, hipMemcpyDeviceToHost));
   return ISL_OK;
+}
+
+isl_status isl_search_batch(const isl_index* idx, const float* queries, uint64_t nq, uint64_t d,
+                            uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dist,
+                            uint32_t* out_count) {
+  return search_batch_host(idx, queries, nq, d, k, ef, out_ids, out_dist, out_count, nullptr);
+}
+
+// ---- two-level search with a PQ filter (extension, see leann_search_two_level) ----
+isl_status isl_index_set_pq_codes(isl_index* idx, const isl_pq* pq, const uint16_t* codes, uint64_t n,
+                                  int32_t mem) {
+  if (!idx || !pq || (!codes && n)) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (n == 0) return isl::fail(ISL_ERR_EMPTY_COLLECTION, "Empty vector collection");
+  if (idx->device < 0) return isl::fail(ISL_ERR_DEVICE, "call isl_index_upload before attaching PQ codes");
+  if (pq->device != idx->device)
+    return isl::fail(ISL_ERR_INVALID_ARGUMENT, "quantizer and index live on different devices");
+  if (n > 0x7FFFFFFFull) return isl::fail(ISL_ERR_UNSUPPORTED, "more than 2^31 - 1 code rows");
+  ISL_TRY(isl::use_device(idx->device));
+  std::lock_guard<std::mutex> lock(idx->mu);
+  if (idx->d_codes) { (void)hipFree(idx->d_codes); idx->d_codes = nullptr; }
+  idx->pq = nullptr;
+  idx->ncodes = 0;
+  const size_t bytes = (size_t)n * pq->m * 2;
+  ISL_HIP(hipMalloc(&idx->d_codes, bytes));
+  ISL_HIP(hipMemcpy(idx->d_codes, codes, bytes, mem == ISL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice));
+  // tables[sq][code] of table_distance (pq.rs:345) would index out of bounds (panic) for a code >= K
+  uint32_t* d_flag = nullptr;
+  ISL_HIP(hipMalloc(&d_flag, 4));
+  ISL_HIP(hipMemset(d_flag, 0, 4));
+  hipLaunchKernelGGL(check_codes_kernel, dim3(1024), dim3(256), 0, nullptr, idx->d_codes, (uint64_t)n * pq->m,
+                     (uint32_t)pq->K, d_flag);
+  uint32_t flag = 0;
+  hipError_t e = hipMemcpy(&flag, d_flag, 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d_flag);
+  if (e != hipSuccess || flag) {
+    (void)hipFree(idx->d_codes);
+    idx->d_codes = nullptr;
+    if (e != hipSuccess) return isl::fail(ISL_ERR_DEVICE, "code check failed: %s", hipGetErrorString(e));
+    return isl::fail(ISL_ERR_PQ, "PQ error: a code is not below num_centroids = %llu", (unsigned long long)pq->K);
+  }
+  idx->pq = pq;
+  idx->ncodes = n;
+  return ISL_OK;
+}
+
+isl_status isl_search_two_level_batch(const isl_index* idx, const float* queries, uint64_t nq, uint64_t d,
+                                      uint64_t k, uint64_t ef, float rerank_ratio, uint64_t* out_ids,
+                                      float* out_dist, uint32_t* out_count) {
+  const TwoLevelCall tl{rerank_ratio};
+  return search_batch_host(idx, queries, nq, d, k, ef, out_ids, out_dist, out_count, &tl);
+}
+
+isl_status isl_search_two_level_batch_device(const isl_index* idx, const float* d_queries, uint64_t nq,
+                                             uint64_t d, uint64_t k, uint64_t ef, float rerank_ratio,
+                                             uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count,
+                                             void* stream) {
+  int done = 0;
+  ISL_TRY(precheck(idx, nq, d, k, d_out_count, true, &done));
+  if (done == 1) return ISL_OK;
+  ISL_TRY(precheck_two_level(idx, d));
+  if (!d_queries || !d_out_count || (k && (!d_out_ids || !d_out_dist)))
+    return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
+  ISL_TRY(isl::use_device(idx->device));
+  std::lock_guard<std::mutex> lock(idx->mu);
+  isl::SearchWorkspace* ws = free_lane(idx);
+  if (!ws) return isl::fail(ISL_ERR_SEARCH, "Search error: every search lane has a call in flight");
+  const TwoLevelCall tl{rerank_ratio};
+  return search_sync(idx, *ws, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count,
+                     (hipStream_t)stream, StreamMode::USER, &tl);
 }
 
 isl_status isl_search(const isl_index* idx, const float* query, uint64_t d, uint64_t k,

@@ -1092,6 +1092,176 @@ float orc_pq_table_distance(const float* tables, size_t m, size_t K, const uint1
 }
 
 /* ------------------------------------------------------------------------- */
+/* EXTENSION: two-level search with a PQ filter                              */
+/* ------------------------------------------------------------------------- */
+/* The reference promises this search (leann.rs:54-56, :855-857) and specifies it
+ * as pseudo-code only (docs/leann-specification.md:223-275, "Algorithm 2"); no
+ * Rust implementation exists, so there is nothing to be bit-identical to.  This
+ * is the definition the device path is tested against.  Where the pseudo-code is
+ * silent the rule is stated here:
+ *   - visited, EQ, R start with the entry point and its exact distance (lines 1-4);
+ *   - every key is the total order (OrderedFloat distance, id) of leann.rs:907-908;
+ *     a distance is canonicalised before use: -0.0 -> +0.0, NaN -> bits 0x7FFFFFFF;
+ *   - EQ holds exactly the members of R that were not expanded yet: an entry
+ *     evicted from R (line 27) is farther than the worst result and would hit the
+ *     break of lines 8-9 when popped; the loop ends when R has no unexpanded
+ *     member (lines 5-9 under the total order);
+ *   - AQ keeps every node ever given an approximate distance, promoted or not
+ *     (that is what makes line 22's "if m not in EQ" meaningful);
+ *     d_approx = ProductQuantizer::table_distance (pq.rs:341-348) on the tables of
+ *     build_distance_tables (pq.rs:307-338);
+ *   - line 19: M = the first ceil(a * |AQ|) entries of AQ in ascending
+ *     (d_approx, id) order, the product taken in f32, at least one entry when AQ is
+ *     not empty; the members of M not promoted before are promoted in that order;
+ *   - exact distances come from DistanceMetric::calculate on the provider's row;
+ *   - apply_pruning_strategy is not part of Algorithm 2 and is not applied;
+ *   - results: R ascending in (distance, id), first k.
+ * Counters: expansions, edges as in orc_leann_search; evals = exact distance
+ * evaluations (entry included); pushes = approximate (table) evaluations.
+ * Errors follow search_with_params (leann.rs:868-896); a neighbour without a
+ * code row, or a promoted id without an embedding row, is NodeNotFound. */
+static float tl_canon(float d) {
+  if (d != d) {
+    union { uint32_t u; float f; } c;
+    c.u = 0x7FFFFFFFu;
+    return c.f;
+  }
+  return d == 0.0f ? 0.0f : d;
+}
+
+typedef struct {
+  item_t it;
+  int flag; /* R: expanded; AQ: promoted */
+} tl_item;
+
+/* inserts into an ascending array (cmp_tuple order); returns the new length */
+static size_t tl_insert(tl_item* a, size_t n, item_t it) {
+  size_t pos = n;
+  while (pos > 0 && cmp_tuple(&it, &a[pos - 1].it) < 0) {
+    a[pos] = a[pos - 1];
+    pos--;
+  }
+  a[pos].it = it;
+  a[pos].flag = 0;
+  return n + 1;
+}
+
+int orc_two_level_search(const orc_csr* g, const orc_leann_params* p, const float* vectors,
+                         uint64_t nvec, size_t d, const float* codebooks, size_t m, size_t K,
+                         size_t dsub, const uint16_t* codes, uint64_t ncodes, const float* query,
+                         size_t qd, size_t k, size_t ef, float rerank_ratio, uint64_t* out_ids,
+                         float* out_dist, size_t* out_count, orc_counters* ctr,
+                         uint64_t* err_payload) {
+  *out_count = 0;
+  orc_counters c = {0, 0, 0, 0};
+  if (ctr) *ctr = c;
+  if (g->num_nodes == 0) return ORC_OK; /* leann.rs:875-877 */
+  if (p->has_dimension && qd != p->dimension) { /* :880-887 */
+    if (err_payload) *err_payload = qd;
+    return ORC_DIMENSION_MISMATCH;
+  }
+  if (!g->has_entry) return ORC_INDEX_NOT_BUILT; /* :889 */
+  if (ef < k) ef = k;                            /* :890 */
+  if (qd != d || qd != m * dsub) { /* distance.rs:39-44, pq.rs:308-313 */
+    if (err_payload) *err_payload = qd != d ? d : m * dsub;
+    return ORC_DIMENSION_MISMATCH;
+  }
+  int status = ORC_OK;
+  float* tables = (float*)malloc(m * K * sizeof(float));
+  orc_pq_build_tables(codebooks, m, K, dsub, query, qd, tables);
+  set_t visited;
+  set_init(&visited);
+  tl_item* R = (tl_item*)malloc((ef + 2) * sizeof(tl_item));
+  size_t rlen = 0, aqlen = 0, aqcap = 1024;
+  tl_item* AQ = (tl_item*)malloc(aqcap * sizeof(tl_item));
+
+  uint64_t entry = g->entry_point;
+  if (entry >= nvec) {
+    if (err_payload) *err_payload = entry;
+    status = ORC_NODE_NOT_FOUND;
+    goto done;
+  }
+  {
+    float ed;
+    orc_distance(p->metric, query, d, vectors + (size_t)entry * d, d, &ed);
+    c.evals = 1;
+    set_insert(&visited, entry);
+    item_t it;
+    it.d = tl_canon(ed);
+    it.id = entry;
+    rlen = tl_insert(R, rlen, it);
+  }
+  for (;;) {
+    size_t e = 0;
+    while (e < rlen && R[e].flag) e++;
+    if (e == rlen) break; /* lines 5-9 */
+    R[e].flag = 1;
+    uint64_t v = R[e].it.id;
+    const uint64_t* nb;
+    size_t deg;
+    if (orc_csr_get_neighbors(g, v, &nb, &deg) != 0) continue; /* leann.rs:227-229 */
+    c.expansions++;
+    c.edges += deg;
+    for (size_t i = 0; i < deg; i++) { /* lines 12-16 */
+      uint64_t n = nb[i];
+      if (!set_insert(&visited, n)) continue;
+      if (n >= ncodes) {
+        if (err_payload) *err_payload = n;
+        status = ORC_NODE_NOT_FOUND;
+        goto done;
+      }
+      item_t it;
+      it.d = tl_canon(orc_pq_table_distance(tables, m, K, codes + (size_t)n * m));
+      it.id = n;
+      c.pushes++;
+      if (aqlen + 1 >= aqcap) {
+        aqcap *= 2;
+        AQ = (tl_item*)realloc(AQ, aqcap * sizeof(tl_item));
+      }
+      aqlen = tl_insert(AQ, aqlen, it);
+    }
+    if (aqlen == 0) continue;
+    float tf = ceilf(rerank_ratio * (float)aqlen); /* line 19 */
+    size_t ntop = tf >= 1.0f ? (size_t)tf : 1; /* NaN and negatives -> 1 */
+    if (tf >= (float)aqlen) ntop = aqlen;
+    if (ntop > aqlen) ntop = aqlen;
+    for (size_t i = 0; i < ntop; i++) { /* lines 21-27 */
+      if (AQ[i].flag) continue;
+      AQ[i].flag = 1;
+      uint64_t mm = AQ[i].it.id;
+      if (mm >= nvec) {
+        if (err_payload) *err_payload = mm;
+        status = ORC_NODE_NOT_FOUND;
+        goto done;
+      }
+      float dd;
+      orc_distance(p->metric, query, d, vectors + (size_t)mm * d, d, &dd);
+      c.evals++;
+      item_t it;
+      it.d = tl_canon(dd);
+      it.id = mm;
+      rlen = tl_insert(R, rlen, it);
+      if (rlen > ef) rlen = ef;
+    }
+  }
+  {
+    size_t n = rlen < k ? rlen : k;
+    for (size_t i = 0; i < n; i++) {
+      out_ids[i] = R[i].it.id;
+      out_dist[i] = R[i].it.d;
+    }
+    *out_count = n;
+  }
+done:
+  if (ctr) *ctr = c;
+  free(tables);
+  free(R);
+  free(AQ);
+  set_free(&visited);
+  return status;
+}
+
+/* ------------------------------------------------------------------------- */
 /* embedding/candle_provider.rs:434-488 (islands' own pooling code)          */
 /* ------------------------------------------------------------------------- */
 void orc_mean_pool_normalize(const float* hidden, const float* mask, size_t B, size_t L, size_t H,

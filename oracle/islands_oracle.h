@@ -192,6 +192,17 @@ int orc_pq_build_tables(const float* codebooks, size_t m, size_t K, size_t dsub,
 float orc_pq_table_distance(const float* tables, size_t m, size_t K,
                             const uint16_t* codes); /* pq.rs:341-348 */
 
+/* ---- EXTENSION: two-level search with a PQ filter ----
+ * docs/leann-specification.md:223-275 (Algorithm 2), promised at leann.rs:54-56 and
+ * :855-857, not implemented by the reference: this restatement of the pseudo-code IS
+ * the definition (rules spelled out in islands_oracle.c).  codes: ncodes rows of m u16. */
+int orc_two_level_search(const orc_csr* g, const orc_leann_params* p, const float* vectors,
+                         uint64_t nvec, size_t d, const float* codebooks, size_t m, size_t K,
+                         size_t dsub, const uint16_t* codes, uint64_t ncodes, const float* query,
+                         size_t qd, size_t k, size_t ef, float rerank_ratio, uint64_t* out_ids,
+                         float* out_dist, size_t* out_count, orc_counters* ctr,
+                         uint64_t* err_payload);
+
 /* ---- embedding/candle_provider.rs:434-488: masked mean-pool + L2 normalise ----
  * hidden: [B][L][H] f32, mask: [B][L] (0/1 as f32). out: [B][H]. */
 void orc_mean_pool_normalize(const float* hidden, const float* mask, size_t B, size_t L, size_t H,

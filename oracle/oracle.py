@@ -243,6 +243,41 @@ def leann_search_batch(g: Csr, vectors, queries, k: int, ef: int, **kw):
     return ids, dist, cnt, tot
 
 
+def two_level_search(g: Csr, vectors, codebooks, codes, query, k: int, ef: int,
+                     rerank_ratio: float, metric: int = COSINE,
+                     dimension: int | None = -1) -> SearchOut:
+    """EXTENSION (docs/leann-specification.md:223-275, Algorithm 2): the definition the
+    device path is tested against -- see islands_oracle.c.  codebooks: [m][K][dsub],
+    codes: [ncodes][m] u16.  counters: evals = exact, pushes = approximate evaluations."""
+    vectors = _f32(vectors)
+    query = _f32(query)
+    cb = _f32(codebooks)
+    codes = np.ascontiguousarray(codes, dtype=np.uint16)
+    nvec, d = vectors.shape
+    m, K, dsub = cb.shape
+    if dimension == -1:
+        dimension = d
+    p = _LeannParams(metric, 0.0, PRUNE_GLOBAL, 0 if dimension is None else 1,
+                     0 if dimension is None else dimension)
+    ids = np.zeros(max(k, 1), dtype=np.uint64)
+    dist = np.zeros(max(k, 1), dtype=np.float32)
+    cnt = C.c_size_t()
+    ctr = _Counters()
+    payload = C.c_uint64()
+    gc = g._c()
+    fn = lib().orc_two_level_search
+    fn.restype = C.c_int
+    st = fn(C.byref(gc), C.byref(p), _p(vectors, C.c_float), C.c_uint64(nvec), C.c_size_t(d),
+            _p(cb, C.c_float), C.c_size_t(m), C.c_size_t(K), C.c_size_t(dsub),
+            _p(codes, C.c_uint16), C.c_uint64(codes.shape[0]), _p(query, C.c_float),
+            C.c_size_t(query.size), C.c_size_t(k), C.c_size_t(ef), C.c_float(rerank_ratio),
+            _p(ids, C.c_uint64), _p(dist, C.c_float), C.byref(cnt), C.byref(ctr),
+            C.byref(payload))
+    n = cnt.value
+    return SearchOut(st, ids[:n].copy(), dist[:n].copy(),
+                     {f: int(getattr(ctr, f)) for f, _ in _Counters._fields_}, payload.value)
+
+
 def leann_build(vectors, m: int = 30, m0: int = 60, ef_construction: int = 128,
                 metric: int = COSINE, high_degree_pruning: bool = True,
                 hub_percentile: float = 0.02, levels=None) -> Csr:

@@ -96,3 +96,79 @@ def leann_search_layer(off, nb, vectors, q, entry, ef):
     out = list(res.data)
     out.sort(key=lambda t: float(t[0]))  # Python sort is stable, like slice::sort_by
     return [t[1] for t in out], [t[0] for t in out]
+
+
+# ---- extension: two-level search (docs/leann-specification.md:223-275, Algorithm 2) ----
+def pq_tables(codebooks, q):
+    """build_distance_tables, pq.rs:307-338: per (subquantizer, centroid) the left-fold sum of
+    (a - b)^2 in f32."""
+    m, K, dsub = codebooks.shape
+    t = np.zeros((m, K), dtype=f32)
+    for j in range(m):
+        sub = q[j * dsub:(j + 1) * dsub]
+        for c in range(K):
+            s = f32(0)
+            for a, b in zip(sub, codebooks[j, c]):
+                df = f32(a - b)
+                s = f32(s + f32(df * df))
+            t[j, c] = s
+    return t
+
+
+def table_distance(tables, codes):
+    s = f32(0)
+    for j, c in enumerate(codes):
+        s = f32(s + tables[j, int(c)])
+    return np.sqrt(s, dtype=f32)
+
+
+def two_level_search(off, nb, vectors, codebooks, codes, q, entry, k, ef, ratio):
+    """Independent restatement of the rules fixed in oracle/islands_oracle.c
+    (orc_two_level_search), written with sets and sorted() instead of arrays."""
+    n = len(off) - 1
+    ef = max(ef, k)
+    tables = pq_tables(codebooks, q)
+    visited = {entry}
+    exact = {entry: cosine(q, vectors[entry])}     # every promoted node
+    expanded = set()
+    approx = {}                                     # AQ: id -> d_approx
+    promoted = set()
+    n_exact, n_approx = 1, 0
+
+    def key(item):
+        d, i = item
+        d = float(d)
+        return (d + 0.0 if d == d else float("inf"), d != d, i)
+
+    def current_r():
+        return sorted(((d, i) for i, d in exact.items()), key=key)[:ef]
+
+    while True:
+        r = current_r()
+        cand = [i for _, i in r if i not in expanded]
+        if not cand:
+            break
+        v = cand[0]
+        expanded.add(v)
+        if v >= n:
+            continue
+        for x in nb[int(off[v]):int(off[v + 1])]:
+            x = int(x)
+            if x in visited:
+                continue
+            visited.add(x)
+            approx[x] = table_distance(tables, codes[x])
+            n_approx += 1
+        if not approx:
+            continue
+        ntop = int(np.ceil(f32(f32(ratio) * f32(len(approx)))))
+        ntop = min(max(ntop, 1), len(approx))
+        order = sorted(((d, i) for i, d in approx.items()), key=key)[:ntop]
+        for _, i in order:
+            if i in promoted:
+                continue
+            promoted.add(i)
+            exact[i] = cosine(q, vectors[i])
+            n_exact += 1
+    r = current_r()[:k]
+    return [i for _, i in r], [d for d, _ in r], n_exact, n_approx
