@@ -1273,10 +1273,26 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
           payload = rl_u(uid, __ffsll((long long)bad) - 1);
           break;
         }
+        // table_distance, pq.rs:341-348: left fold over the subquantizers.  Eight codes per 16-byte
+        // load, their eight table entries fetched together, then added in order.
         float s = 0.0f;
         if (lane < nu) {
           const uint16_t* cr = p.tl_codes + (uint64_t)uid * m;
-          for (uint32_t j = 0; j < m; ++j) s += tables[(uint64_t)j * K + cr[j]];
+          if ((m & 7u) == 0) {
+            const uint4* cv = reinterpret_cast<const uint4*>(cr);
+#pragma unroll 2
+            for (uint32_t j0 = 0; j0 < m; j0 += 8) {
+              const uint4 c8 = cv[j0 >> 3];
+              const float* tb = tables + (uint64_t)j0 * K;
+              const float t0 = tb[c8.x & 0xFFFFu], t1 = tb[K + (c8.x >> 16)];
+              const float t2 = tb[2 * K + (c8.y & 0xFFFFu)], t3 = tb[3 * K + (c8.y >> 16)];
+              const float t4 = tb[4 * K + (c8.z & 0xFFFFu)], t5 = tb[5 * K + (c8.z >> 16)];
+              const float t6 = tb[6 * K + (c8.w & 0xFFFFu)], t7 = tb[7 * K + (c8.w >> 16)];
+              s += t0; s += t1; s += t2; s += t3; s += t4; s += t5; s += t6; s += t7;
+            }
+          } else {
+            for (uint32_t j = 0; j < m; ++j) s += tables[(uint64_t)j * K + cr[j]];
+          }
         }
         const float ad = sqrtf(s);
         const uint64_t key = ((uint64_t)ordkey(ad) << 32) | ((uint64_t)uid << 1);
@@ -1292,18 +1308,9 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
       uint32_t ntop = tf >= 1.0f ? (tf >= (float)aq_total ? aq_total : (uint32_t)tf) : 1u;
       if (ntop > aq_total) ntop = aq_total;
       if (ntop > wlen) { status = QS_SCRATCH; payload = 7; break; }
-      for (uint32_t c = 0; c < ntop && status == QS_OK; c += 64) {
-        const uint32_t i = c + lane;
-        const uint64_t x = i < ntop ? win[i] : ~0ull;
-        const bool un = i < ntop && !(x & 1ull);
-        const uint64_t um = ballot(un);
-        const uint32_t pc = (uint32_t)__popcll(um);
-        if (!pc) continue;
-        const uint32_t rank = (uint32_t)__popcll(um & ((1ull << lane) - 1ull));
-        if (un) {
-          win[i] = x | 1ull;
-          scratch[rank] = (uint32_t)(x >> 1) & ID_MASK;
-        }
+      // the unpromoted members of M are collected over the whole prefix (up to 64 at a time), so
+      // that their rows are fetched in one distance pass and merged into R at once
+      auto promote = [&](uint32_t pc) {
         wave_sync();
         const uint32_t pid = lane < pc ? scratch[lane] : 0u;
         wave_sync();
@@ -1311,16 +1318,37 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
         if (bad) {
           status = QS_NODE_NOT_FOUND;
           payload = rl_u(pid, __ffsll((long long)bad) - 1);
-          break;
+          return;
         }
-        if (!rows_present(p, pid, pc)) { status = QS_BLOCKED; break; }
+        if (!rows_present(p, pid, pc)) { status = QS_BLOCKED; return; }
         cV += pc;
         const float r_aux = (METRIC == METRIC_COSINE_PRE && lane < pc) ? p.norm2[pid] : 0.0f;
         const float nd = direct_distances<METRIC, ROWT>(emb, p.stride, p.d, pid, pc, qs, q_norm, r_aux);
         const uint64_t rkey = ((uint64_t)ordkey(nd) << 32) | ((uint64_t)pid << 1);
         rlen = tl_merge(res, rlen, rkey, pc, nbuf);
-        if (rlen > ef) rlen = ef;  // line 26-27
+        if (rlen > ef) rlen = ef;  // lines 26-27
+      };
+      uint32_t pend = 0;
+      for (uint32_t c = 0; c < ntop && status == QS_OK; c += 64) {
+        const uint32_t i = c + lane;
+        const uint64_t x = i < ntop ? win[i] : ~0ull;
+        const bool un = i < ntop && !(x & 1ull);
+        const uint64_t um = ballot(un);
+        const uint32_t pc = (uint32_t)__popcll(um);
+        if (!pc) continue;
+        if (pend + pc > 64) {
+          promote(pend);
+          pend = 0;
+          if (status != QS_OK) break;
+        }
+        const uint32_t rank = (uint32_t)__popcll(um & ((1ull << lane) - 1ull));
+        if (un) {
+          win[i] = x | 1ull;
+          scratch[pend + rank] = (uint32_t)(x >> 1) & ID_MASK;
+        }
+        pend += pc;
       }
+      if (pend && status == QS_OK) promote(pend);
     }
 
     const uint32_t outn = rlen < p.k ? rlen : p.k;
@@ -1435,6 +1463,7 @@ void launch_two_level(int metric, uint32_t grid, size_t lds, hipStream_t st, con
 // Two-level search: LDS of one wave = visited table + approximate-queue window + R + staging + query
 struct TwoLevelCall {
   float ratio;
+  uint32_t window_scale = 1;  // the window grows 4x per retry after a query outgrew it
 };
 size_t two_level_lds(uint32_t hbits, uint32_t wcap, uint32_t ef, uint32_t d) {
   return ((size_t)4 << hbits) + (size_t)(wcap + 64) * 8 + (size_t)((ef + 63) / 64 * 64 + 64) * 8 + 64 * 8 +
@@ -1591,7 +1620,7 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
     // node count and, in practice, by a few dozen times ef
     use_fast = false;
     const float a = tl->ratio > 0.0f ? std::min(tl->ratio, 1.0f) : 0.0f;
-    const double bound = (double)std::min<uint64_t>(idx->ncodes, (uint64_t)128 * ef);
+    const double bound = (double)std::min<uint64_t>(idx->ncodes, (uint64_t)32 * ef * tl->window_scale);
     const uint64_t want = (uint64_t)(a * bound) + 64;
     tl_wcap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((want + 63) / 64 * 64, 256), 16384);
     while (tl_wcap > 256 && two_level_lds(fg.hbits, tl_wcap, ef, (uint32_t)d) > 160 * 1024) tl_wcap -= 64;
@@ -1774,7 +1803,8 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
 
 // Waits for the call in flight on `ws`, folds its counters into the index statistics and turns
 // per-query failures into the CoreError the reference's sequential map would have returned.
-isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws, uint32_t* misses = nullptr) {
+isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws, uint32_t* misses = nullptr,
+                         bool* window_short = nullptr) {
   if (!ws.busy) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "no search in flight for this token");
   ws.busy = false;
   const uint64_t nq = ws.nq_inflight;
@@ -1847,6 +1877,11 @@ isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws, uint32_
       ISL_HIP(hipMemcpy(&node, ws.payload + i, 8, hipMemcpyDeviceToHost));
       return isl::fail_node(node);
     }
+    if (status[i] == QS_SCRATCH && window_short) {  // two-level search: 7 = the queue window was too small
+      uint64_t why = 0;
+      ISL_HIP(hipMemcpy(&why, ws.payload + i, 8, hipMemcpyDeviceToHost));
+      *window_short = why == 7;
+    }
     if (status[i] == QS_SCRATCH)
       return isl::fail(ISL_ERR_SEARCH, "Search error: device scratch exhausted for query %llu (candidate heap, "
                        "visited table or the two-level search's approximate-queue window)",
@@ -1894,9 +1929,18 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
                        uint64_t nq, uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_ids,
                        float* d_dist, uint32_t* d_count, hipStream_t user_stream, StreamMode mode,
                        const TwoLevelCall* tl = nullptr) {
+  // two-level search: a query whose approximate queue outgrew the LDS window is never answered
+  // differently, the batch is run again with a window four times the size
+  TwoLevelCall tcall;
+  if (tl) { tcall = *tl; tl = &tcall; }
   if (!idx->recompute) {
-    ISL_TRY(search_enqueue(idx, ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, user_stream, mode, tl));
-    return search_finish(idx, ws);
+    for (;;) {
+      ISL_TRY(search_enqueue(idx, ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, user_stream, mode, tl));
+      bool window_short = false;
+      const isl_status st = search_finish(idx, ws, nullptr, tl ? &window_short : nullptr);
+      if (st == ISL_ERR_SEARCH && window_short && tcall.window_scale < 64) { tcall.window_scale *= 4; continue; }
+      return st;
+    }
   }
   const uint64_t cap = std::min<uint64_t>(nq * 64 + 64, 0xFFFFFFF0ull);
   if (ws.miss_cap < cap) {
@@ -1917,7 +1961,10 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
   for (;;) {
     ISL_TRY(search_enqueue(idx, ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, user_stream, mode, tl));
     uint32_t misses = 0;
-    ISL_TRY(search_finish(idx, ws, &misses));
+    bool window_short = false;
+    const isl_status fst = search_finish(idx, ws, &misses, tl ? &window_short : nullptr);
+    if (fst == ISL_ERR_SEARCH && window_short && tcall.window_scale < 64) { tcall.window_scale *= 4; continue; }
+    ISL_TRY(fst);
     kernel_ms += idx->stats.kernel_ms;
     rounds += 1;
     if (!misses) break;

@@ -508,6 +508,37 @@ def build_graph(x: torch.Tensor, m0: int = 60, k0: int = 28, k_upper: int = 20, 
     return offsets, neighbours, entry
 
 
+def train_pq(x: torch.Tensor, m: int, K: int = 256, iters: int = 6, seed: int = 13,
+             sample: int = 262144, chunk: int = 1 << 18):
+    """Harness only (PQ training, pq.rs:362-463, is build-time and draws from thread_rng): Lloyd
+    iterations per subquantizer on a sample of the rows, then the code of every row = its nearest
+    centroid under squared L2.  Returns (codebooks [m][K][dsub] f32, codes [n][m] u16) on x's
+    device.  The codes are INPUT data of the two-level search; nothing is compared with them."""
+    n, d = x.shape
+    dsub = d // m
+    g = torch.Generator(device=x.device)
+    g.manual_seed(seed)
+    pick = torch.randperm(n, generator=g, device=x.device)[:min(sample, n)]
+    xs = x[pick]
+    cb = torch.empty((m, K, dsub), dtype=torch.float32, device=x.device)
+    codes = torch.empty((n, m), dtype=torch.int16, device=x.device)
+    for j in range(m):
+        sub = xs[:, j * dsub:(j + 1) * dsub].contiguous()
+        cent = sub[torch.randperm(sub.shape[0], generator=g, device=x.device)[:K]].clone()
+        if cent.shape[0] < K:
+            cent = torch.cat([cent, cent[:1].expand(K - cent.shape[0], -1)])
+        for _ in range(iters):
+            a = torch.cdist(sub, cent).argmin(1)
+            sums = torch.zeros_like(cent).index_add_(0, a, sub)
+            cnt = torch.zeros(K, device=x.device).index_add_(0, a, torch.ones_like(a, dtype=torch.float32))
+            cent = torch.where(cnt[:, None] > 0, sums / cnt[:, None].clamp_min(1.0), cent)
+        cb[j] = cent
+        for s in range(0, n, chunk):
+            blk = x[s:s + chunk, j * dsub:(j + 1) * dsub]
+            codes[s:s + chunk, j] = torch.cdist(blk, cent).argmin(1).to(torch.int16)
+    return cb, codes
+
+
 def graph_stats(offsets: torch.Tensor) -> dict:
     deg = (offsets[1:] - offsets[:-1]).float()
     return {"nodes": int(deg.numel()), "edges": int(offsets[-1].item()),

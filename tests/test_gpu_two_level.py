@@ -177,3 +177,19 @@ def test_two_level_with_recompute_provider(orc):
         c = int(got[2][i])
         assert got[0][i, :c].tolist() == r.ids.tolist()
     del plain
+
+
+def test_two_level_window_retry(orc):
+    """A small ef sizes the LDS window of the approximate queue small; ratio 1 over long adjacency
+    rows outgrows it, and the batch is answered by a run with a larger window -- same results."""
+    n, d, m, K = 3000, 32, 8, 32
+    v = clustered_vectors(n, d, 71)
+    off, nb = random_csr(n, 64, 12)
+    cb, codes = make_pq(v, m, K, 13)
+    csr = orc.Csr(off, nb, entry_point=1)
+    idx = make_index(csr, v)
+    pq = attach_pq(idx, cb, codes)
+    q = clustered_vectors(8, d, 72)
+    st = assert_same(orc, idx, csr, v, cb, codes, q, 3, 6, 1.0)
+    assert st["pushes"] / 8 > 256          # |AQ| beyond the first window (256 entries)
+    del pq
