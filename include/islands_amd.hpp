@@ -186,6 +186,22 @@ class LeannIndex {
     for (uint32_t i = 0; i < cnt; i++) out.emplace_back(ids[i], dist[i]);
     return out;
   }
+  // extension: the two-level search leann.rs:855-857 asks for (docs/leann-specification.md:223-275);
+  // codes = ProductQuantizer::encode of every node, [n][m]; the quantizer is borrowed
+  void attach_pq_codes(const isl_pq* pq, const std::vector<uint16_t>& codes, uint64_t n) {
+    check(isl_index_set_pq_codes(h_, pq, codes.data(), n, ISL_MEM_HOST));
+  }
+  std::vector<std::pair<uint64_t, float>> search_two_level(const std::vector<float>& query, uint64_t k,
+                                                           uint64_t ef, float rerank_ratio) const {
+    std::vector<uint64_t> ids(k ? k : 1);
+    std::vector<float> dist(k ? k : 1);
+    uint32_t cnt = 0;
+    check(isl_search_two_level_batch(h_, query.data(), 1, query.size(), k, ef, rerank_ratio, ids.data(),
+                                     dist.data(), &cnt));
+    std::vector<std::pair<uint64_t, float>> out;
+    for (uint32_t i = 0; i < cnt; i++) out.emplace_back(ids[i], dist[i]);
+    return out;
+  }
   isl_index* handle() const { return h_; }
 
  private:
