@@ -392,6 +392,15 @@ isl_status isl_hnsw_search_batch(const isl_hnsw* h, const float* queries, uint64
  * exact_path = queries in which two equal distances met and the heap-exact kernel decided. */
 isl_status isl_hnsw_last_stats(const isl_hnsw* h, isl_search_stats* out);
 
+/* isl_distance_matrix for bf16 queries and rows (bit patterns; BASELINE config 5: d = 4096 bf16): the
+ * same batch_calculate (distance.rs:32-34) over the exact float32 images of the stored values, on
+ * the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, float32 accumulation).  out [nq][n] f32.
+ * d must be a multiple of 64; Manhattan -> Unsupported.  Agreement with the sequential sums:
+ * float32 rounding of the accumulation order (<= 1e-5 on normalised rows), not bit for bit. */
+isl_status isl_distance_matrix_bf16(int32_t metric, const uint16_t* queries, uint64_t nq, const uint16_t* rows,
+                                    uint64_t n, uint64_t d, float* out, int32_t mem, int32_t device,
+                                    void* stream);
+
 /* ---- EXTENSION: two-level search with a PQ filter ----
  * "Algorithm 2: Two-Level Search with Hybrid Distance", docs/leann-specification.md:223-275; the
  * reference promises it (leann.rs:54-56, :855-857: "a two-level search with PQ filtering should

@@ -114,6 +114,16 @@ def distance_matrix(metric: DistanceMetric, queries, rows, device: int = 0) -> n
     return out
 
 
+def distance_matrix_bf16(metric: DistanceMetric, queries_bits, rows_bits, device: int = 0) -> np.ndarray:
+    """distance_matrix over bf16 bit patterns (u16) on the bf16 matrix cores -> [nq, n] f32."""
+    q = np.ascontiguousarray(queries_bits, dtype=np.uint16)
+    r = np.ascontiguousarray(rows_bits, dtype=np.uint16)
+    out = np.zeros((q.shape[0], r.shape[0]), dtype=np.float32)
+    _check(_ffi.lib().isl_distance_matrix_bf16(int(metric), _ptr(q), q.shape[0], _ptr(r), r.shape[0],
+                                               q.shape[1], _ptr(out), MEM_HOST, device, None))
+    return out
+
+
 def bruteforce_topk(metric: DistanceMetric, queries, rows, k: int, device: int = 0):
     """Exact k nearest rows per query (ids, distances, counts), ties towards the smaller id."""
     q, r = _f32(queries), _f32(rows)

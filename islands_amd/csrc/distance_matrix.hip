@@ -6,6 +6,7 @@
 // rows), not bit for bit -- the traversal keeps the exact-order kernels.
 #include "device_common.cuh"
 #include "gemm_f32.cuh"
+#include "gemm_bf16.cuh"
 
 #include <algorithm>
 #include <vector>
@@ -21,6 +22,21 @@ __global__ __launch_bounds__(64) void sumsq_rows_kernel(const float* __restrict_
   if (row >= n) return;
   float s = 0.0f;
   for (uint32_t j = threadIdx.x; j < d; j += 64) { float v = x[row * stride + j]; s += v * v; }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  if (threadIdx.x == 0) out[row] = s;
+}
+
+// the same for bf16 rows (their exact f32 images are squared)
+__global__ __launch_bounds__(64) void sumsq_rows_bf16_kernel(const uint16_t* __restrict__ x, uint64_t n, uint32_t d,
+                                                             float* __restrict__ out) {
+  const uint64_t row = blockIdx.x;
+  if (row >= n) return;
+  float s = 0.0f;
+  for (uint32_t j = threadIdx.x; j < d; j += 64) {
+    const float v = __uint_as_float((uint32_t)x[row * d + j] << 16);
+    s += v * v;
+  }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
   if (threadIdx.x == 0) out[row] = s;
@@ -115,9 +131,64 @@ isl_status launch_distance_gemm(int32_t metric, const float* dq, const float* dr
   return ISL_OK;
 }
 
+isl_status launch_distance_gemm_bf16(int32_t metric, const uint16_t* dq, const uint16_t* dr, const float* qn,
+                                     const float* rn, float* dout, uint64_t nq, uint64_t n, uint64_t d,
+                                     uint64_t ldc, hipStream_t st) {
+  const __bf16* q = reinterpret_cast<const __bf16*>(dq);
+  const __bf16* r = reinterpret_cast<const __bf16*>(dr);
+  switch (metric) {
+    case ISL_METRIC_COSINE: launch_gemm_bf16_distance<EPI_COSINE>(q, r, rn, qn, dout, nq, n, d, ldc, st); break;
+    case ISL_METRIC_DOT: launch_gemm_bf16_distance<EPI_DOT>(q, r, nullptr, nullptr, dout, nq, n, d, ldc, st); break;
+    case ISL_METRIC_EUCLIDEAN: launch_gemm_bf16_distance<EPI_EUCLIDEAN>(q, r, rn, qn, dout, nq, n, d, ldc, st); break;
+    default:
+      return isl::fail(ISL_ERR_UNSUPPORTED, "the Manhattan distance is not a contraction: use isl_distance_batch");
+  }
+  ISL_HIP(hipGetLastError());
+  return ISL_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+// bf16 rows and queries (BASELINE config 5): products of two bf16 values are exact in float32, the
+// sums run in the accumulation order of v_mfma_f32_32x32x16_bf16.  d must be a multiple of 64.
+isl_status isl_distance_matrix_bf16(int32_t metric, const uint16_t* queries, uint64_t nq, const uint16_t* rows,
+                                    uint64_t n, uint64_t d, float* out, int32_t mem, int32_t device,
+                                    void* stream) {
+  if (nq == 0 || n == 0) return ISL_OK;
+  if (!queries || !rows || !out) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
+  if (d == 0) return isl::fail(ISL_ERR_EMPTY_COLLECTION, "Empty vector collection");
+  if (d % 64) return isl::fail(ISL_ERR_UNSUPPORTED, "bf16 distance matrix: the dimension must be a multiple of 64");
+  if (nq > 0xFFFFFFFFull || n > 0xFFFFFFFFull || ((nq + 127) / 128) * ((n + 127) / 128) >= 0x7FFFFFFFull)
+    return isl::fail(ISL_ERR_UNSUPPORTED, "matrix too large for one launch: split the rows");
+  ISL_TRY(isl::use_device(device));
+  hipStream_t st = (hipStream_t)stream;
+  Staged s;
+  const uint16_t *dq = queries, *dr = rows;
+  float* dout = out;
+  if (mem == ISL_MEM_HOST) {
+    uint16_t* a = (uint16_t*)s.alloc(nq * d * 2);
+    uint16_t* b = (uint16_t*)s.alloc(n * d * 2);
+    dout = (float*)s.alloc(nq * n * 4);
+    if (!a || !b || !dout) return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed");
+    ISL_HIP(hipMemcpyAsync(a, queries, nq * d * 2, hipMemcpyHostToDevice, st));
+    ISL_HIP(hipMemcpyAsync(b, rows, n * d * 2, hipMemcpyHostToDevice, st));
+    dq = a;
+    dr = b;
+  }
+  if (((uintptr_t)dq & 15) || ((uintptr_t)dr & 15))
+    return isl::fail(ISL_ERR_INVALID_ARGUMENT, "bf16 matrices must be 16-byte aligned");
+  float* qn = (float*)s.alloc(nq * 4);
+  float* rn = (float*)s.alloc(n * 4);
+  if (!qn || !rn) return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed");
+  hipLaunchKernelGGL(sumsq_rows_bf16_kernel, dim3((uint32_t)nq), dim3(64), 0, st, dq, nq, (uint32_t)d, qn);
+  hipLaunchKernelGGL(sumsq_rows_bf16_kernel, dim3((uint32_t)n), dim3(64), 0, st, dr, n, (uint32_t)d, rn);
+  ISL_TRY(launch_distance_gemm_bf16(metric, dq, dr, qn, rn, dout, nq, n, d, n, st));
+  if (mem == ISL_MEM_HOST) ISL_HIP(hipMemcpyAsync(out, dout, nq * n * 4, hipMemcpyDeviceToHost, st));
+  ISL_HIP(hipStreamSynchronize(st));
+  return ISL_OK;
+}
 
 isl_status isl_distance_matrix(int32_t metric, const float* queries, uint64_t nq, const float* rows,
                                uint64_t n, uint64_t d, float* out, int32_t mem, int32_t device,

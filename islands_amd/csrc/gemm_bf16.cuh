@@ -150,17 +150,156 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const void* __restrict__ Av,
     }
 }
 
+// Same contraction with both operands staged by LDS-DMA (global_load_lds_dwordx4: global -> LDS
+// with no register stop) into two 32 KiB buffers: the slab k+1 is in flight while slab k feeds
+// the matrix cores, one barrier per slab.  The DMA writes lane-linear images (a wave
+// instruction fills 8 rows of 128 bytes), so the bank-conflict swizzle is applied to the SOURCE
+// address: LDS chunk c of row r holds the row's 16-byte chunk c ^ (r & 7), and the fragment
+// reads look their chunk up under the same XOR.  Requirements (host-checked): A and W bf16,
+// K % 64 == 0; rows past M / N are clamped (their products are never stored).  Workgroup ids are
+// remapped so that the column tiles of one row tile share an XCD (its L2 then serves A once).
+typedef __attribute__((address_space(3))) void isl_lds_void;
+typedef const __attribute__((address_space(1))) void isl_glb_void;
+
+template <int ACT, bool RES, bool C16>
+__global__ __launch_bounds__(256) void gemm_tn_bf16_dma(const __bf16* __restrict__ A,
+                                                        const __bf16* __restrict__ W,
+                                                        const float* __restrict__ bias,
+                                                        const float* __restrict__ R, void* __restrict__ Cv,
+                                                        uint32_t M, uint32_t N, uint32_t K, uint32_t ntn,
+                                                        uint64_t ldc) {
+  float* C = reinterpret_cast<float*>(Cv);
+  __bf16* Ch = reinterpret_cast<__bf16*>(Cv);
+  // [buffer][A | W][128 rows][64 bf16]
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 2 * BM * HBK * 2];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware, bijective remap of the linear workgroup id (8 XCDs, round-robin dispatch)
+  const uint32_t nwg = gridDim.x, orig = blockIdx.x;
+  const uint32_t q8 = nwg / 8, r8 = nwg % 8, xcd = orig % 8;
+  const uint32_t wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + orig / 8;
+  // grouped order inside an XCD's range: the ~64 workgroups resident on an XCD (32 CUs x 2) cover
+  // 8 row tiles x 8 column tiles, whose A and W slabs (3 MiB at K = 768) stay in its 4 MiB L2
+  const uint32_t ntm = nwg / ntn;
+  constexpr uint32_t GM = 8;
+  const uint32_t group = wgid / (GM * ntn), in_group = wgid % (GM * ntn);
+  const uint32_t gm = ntm - group * GM < GM ? ntm - group * GM : GM;
+  const uint64_t m0 = (uint64_t)(group * GM + in_group % gm) * BM, n0 = (uint64_t)(in_group / gm) * BN;
+  const uint32_t wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  // staging: instruction i of wave w fills LDS chunks [(4 i + w) * 64, + 64) of a 16 KiB image;
+  // chunk = (row, c) with row = chunk / 8
+  const __bf16* asrc[4];
+  const __bf16* wsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t chunk = (4u * i + wave) * 64u + lane, row = chunk >> 3, c = (chunk & 7u) ^ (row & 7u);
+    const uint64_t ra = m0 + row < M ? m0 + row : (uint64_t)M - 1;
+    const uint64_t rw = n0 + row < N ? n0 + row : (uint64_t)N - 1;
+    asrc[i] = A + ra * K + c * 8u;
+    wsrc[i] = W + rw * K + c * 8u;
+  }
+  auto issue = [&](uint32_t k0, uint32_t buf) {
+    unsigned char* ab = lds + buf * (2 * BM * HBK * 2);
+    unsigned char* wb = ab + BM * HBK * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t off = (4u * i + wave) * 1024u;  // wave-uniform destination, lanes follow linearly
+      __builtin_amdgcn_global_load_lds((isl_glb_void*)(asrc[i] + k0), (isl_lds_void*)(ab + off), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((isl_glb_void*)(wsrc[i] + k0), (isl_lds_void*)(wb + off), 16, 0, 0);
+    }
+  };
+  const uint32_t kh = lane >> 5, c32 = lane & 31;
+  const uint32_t nk = K / HBK;
+  issue(0, 0);
+  for (uint32_t kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of slab kt has landed
+    __syncthreads();  // everyone's share has; everyone is done reading the other buffer
+    if (kt + 1 < nk) issue((kt + 1) * HBK, (kt + 1) & 1);
+    const unsigned char* ab = lds + (kt & 1) * (2 * BM * HBK * 2);
+    const unsigned char* wb = ab + BM * HBK * 2;
+#pragma unroll
+    for (int ks = 0; ks < HBK / 16; ++ks) {
+      const uint32_t cl = 2 * ks + kh;  // logical 16-byte chunk of the row
+      const uint32_t rb0 = wn + c32, rb1 = wn + 32 + c32;
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wb + rb0 * 128u + ((cl ^ (rb0 & 7u)) << 4));
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wb + rb1 * 128u + ((cl ^ (rb1 & 7u)) << 4));
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint32_t ra = wm + 32 * i + c32;
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ab + ra * 128u + ((cl ^ (ra & 7u)) << 4));
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[i][1], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint64_t n = n0 + wn + j * 32 + c32;
+      if (n >= N) continue;
+      const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint64_t m = m0 + wm + i * 32 + 8 * (r / 4) + 4 * kh + (r % 4);
+        if (m >= M) continue;
+        float v = acc[i][j][r];
+        if (ACT <= 2) {
+          v += bv;
+          if (ACT == 1) v = gelu_erf_f(v);
+          if (ACT == 2) v = gelu_tanh_f(v);
+          if (RES) v += R[m * N + n];
+        } else if (ACT == EPI_COSINE) {  // bias = |w_n|^2 per column, R = |a_m|^2 per row
+          const float norm = sqrtf(R[m] * bv);
+          v = norm == 0.0f ? 1.0f : 1.0f - v / norm;
+        } else if (ACT == EPI_DOT) {
+          v = -v;
+        } else if (ACT == EPI_EUCLIDEAN) {  // |a|^2 + |w|^2 - 2 a.w, clamped
+          v = R[m] + bv - 2.0f * v;
+          v = sqrtf(v > 0.0f ? v : 0.0f);
+        }
+        if constexpr (C16) Ch[m * N + n] = (__bf16)v;
+        else C[(uint64_t)m * ldc + n] = v;
+      }
+    }
+}
+
 template <int ACT, bool RES, bool A16, bool C16>
 void launch_gemm_bf16(const void* A, const __bf16* W, const float* bias, const float* R, void* C,
                       uint64_t M, uint64_t N, uint64_t K, hipStream_t st) {
   // MF = 4 (256-row tiles, 128 x 64 per wave: 6 LDS operand reads per 8 MFMAs instead of 4 per 4)
   // was measured slower: 272 registers leave one wave per SIMD (27 ms against 18 ms end to end)
+  static const bool no_dma = getenv("ISL_GEMM_NO_DMA") != nullptr;  // A/B switch for measurements
+  if constexpr (A16) {
+    const uint64_t ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
+    if (!no_dma && K % HBK == 0 && ntm * ntn < 0x7FFFFFFFull && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0) {
+      hipLaunchKernelGGL((gemm_tn_bf16_dma<ACT, RES, C16>), dim3((uint32_t)(ntm * ntn)), dim3(256), 0, st,
+                         (const __bf16*)A, W, bias, R, C, (uint32_t)M, (uint32_t)N, (uint32_t)K, (uint32_t)ntn,
+                         (uint64_t)N);
+      return;
+    }
+  }
   dim3 grid((uint32_t)((N + BN - 1) / BN), (uint32_t)((M + BM - 1) / BM));
   hipLaunchKernelGGL((gemm_tn_bf16<ACT, RES, A16, C16, 2>), grid, dim3(256), 0, st, A, W, bias, R, C,
                      (uint32_t)M, (uint32_t)N, (uint32_t)K);
 }
 
-__global__ void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, uint64_t n) {
+// Distance epilogues (EPI_COSINE / EPI_DOT / EPI_EUCLIDEAN) over bf16 queries and rows: out [M][ldc] f32.
+template <int EPI>
+void launch_gemm_bf16_distance(const __bf16* Q, const __bf16* Rows, const float* row_norm2, const float* q_norm2,
+                               float* out, uint64_t M, uint64_t N, uint64_t K, uint64_t ldc, hipStream_t st) {
+  const uint64_t ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm_tn_bf16_dma<EPI, false, false>), dim3((uint32_t)(ntm * ntn)), dim3(256), 0, st, Q, Rows,
+                     row_norm2, q_norm2, out, (uint32_t)M, (uint32_t)N, (uint32_t)K, (uint32_t)ntn, ldc);
+}
+
+static __global__ void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = (__bf16)src[i];
 }

@@ -429,3 +429,29 @@ def test_randomised_differential_slice(orc):
     for case in range(120):
         exact += fuzz_parity.one_case(rng, case)["exact_path"]
     assert exact > 0  # the slice reaches the heap-exact kernel too
+
+
+@pytest.mark.parametrize("metric", [ia.DistanceMetric.Cosine, ia.DistanceMetric.DotProduct,
+                                    ia.DistanceMetric.Euclidean])
+@pytest.mark.parametrize("nq,n,d", [(5, 300, 128), (130, 257, 768), (33, 200, 4096)])
+def test_distance_matrix_bf16_matches_batch_calculate(orc, metric, nq, n, d):
+    """bf16 rows and queries (BASELINE config 5) on the bf16 matrix cores against the reference's
+    sequential float32 sums over the same (exactly widened) values: 1e-5 on normalised rows."""
+    def to_bf16(x):
+        b = (x.view(np.uint32) >> 16).astype(np.uint16)
+        return b, (b.astype(np.uint32) << 16).view(np.float32)
+    rb, rw = to_bf16(clustered_vectors(n, d, 3))
+    qb, qw = to_bf16(clustered_vectors(nq, d, 4))
+    got = ia.distance_matrix_bf16(metric, qb, rb)
+    for i in range(nq):
+        want = orc.batch_distance(int(metric), qw[i], rw)
+        if metric == ia.DistanceMetric.Euclidean:
+            assert np.abs(got[i] ** 2 - want ** 2).max() < 1e-5
+        else:
+            assert np.abs(got[i] - want).max() < 1e-5
+    with pytest.raises(ia.CoreError) as e:
+        ia.distance_matrix_bf16(ia.DistanceMetric.Manhattan, qb, rb)
+    assert e.value.kind == "Unsupported"
+    with pytest.raises(ia.CoreError) as e:
+        ia.distance_matrix_bf16(metric, qb[:, :40], rb[:, :40])
+    assert e.value.kind == "Unsupported"

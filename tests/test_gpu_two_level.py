@@ -193,3 +193,23 @@ def test_two_level_window_retry(orc):
     st = assert_same(orc, idx, csr, v, cb, codes, q, 3, 6, 1.0)
     assert st["pushes"] / 8 > 256          # |AQ| beyond the first window (256 entries)
     del pq
+
+
+def test_two_level_config5_shape(orc):
+    """BASELINE config 5's shape at a small node count: d = 4096, bf16 rows, PQ m = 64 (dsub = 64),
+    K = 256 -- the PQ re-rank path over the plain search's rows."""
+    n, d, m, K = 700, 4096, 64, 256
+    v = clustered_vectors(n, d, 81, per_cluster=35)
+    vb = (v.view(np.uint32) >> 16).astype(np.uint16)
+    vw = (vb.astype(np.uint32) << 16).view(np.float32)
+    off, nb = knn_graph(vw, 14, seed=6)
+    cb, codes = make_pq(vw, m, K, 14)
+    csr = orc.Csr(off, nb, entry_point=0)
+    g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels,
+                    entry_point=0, num_nodes=n, degree_counts=csr.degree_counts)
+    idx = ia.LeannIndex.from_csr(g, None, dimension=d).upload(0)
+    idx.set_embeddings_bf16(vb)
+    pq = attach_pq(idx, cb, codes)
+    q = clustered_vectors(6, d, 82, per_cluster=35)
+    assert_same(orc, idx, csr, vw, cb, codes, q, 10, 48, 0.25)
+    del pq

@@ -58,6 +58,9 @@ def main():
     step = 2048
     for o in range(0, N, step):
         emb[o:o + step] = enc.embed(tok[o:o + step].astype(np.int64))
+        if (o // step) % 256 == 255:
+            print(f"[recompute_bench] encoded {o + step} of {N} nodes, {time.time() - t0:.0f}s",
+                  file=sys.stderr, flush=True)
     t_all = time.time() - t0
     dev = torch.device("cuda:0")
     x = torch.from_numpy(emb).to(dev)
@@ -78,6 +81,7 @@ def main():
         del codes
     del x
     torch.cuda.synchronize()
+    print("[recompute_bench] graph and index ready, searching", file=sys.stderr, flush=True)
     t0 = time.time()
     if pq is not None:
         ids, dist, cnt = idx.search_two_level_batch(q, args.k, args.ef, args.two_level)
