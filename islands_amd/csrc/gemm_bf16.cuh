@@ -154,65 +154,76 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const void* __restrict__ Av,
 // with no register stop) into two 32 KiB buffers: the slab k+1 is in flight while slab k feeds
 // the matrix cores, one barrier per slab.  The DMA writes lane-linear images (a wave
 // instruction fills 8 rows of 128 bytes), so the bank-conflict swizzle is applied to the SOURCE
-// address: LDS chunk c of row r holds the row's 16-byte chunk c ^ (r & 7), and the fragment
-// reads look their chunk up under the same XOR.  Requirements (host-checked): A and W bf16,
+// address: LDS chunk c of row r holds the row's 16-byte chunk c ^ ((r >> 1) & 7), and the fragment
+// reads look their chunk up under the same XOR (16 consecutive rows at one logical chunk then
+// touch 16 different 16-byte slots of the 256-byte bank row).  Requirements (host-checked): A and W bf16,
 // K % 64 == 0; rows past M / N are clamped (their products are never stored).  Workgroup ids are
 // remapped so that the column tiles of one row tile share an XCD (its L2 then serves A once).
 typedef __attribute__((address_space(3))) void isl_lds_void;
 typedef const __attribute__((address_space(1))) void isl_glb_void;
 
-template <int ACT, bool RES, bool C16>
-__global__ __launch_bounds__(256) void gemm_tn_bf16_dma(const __bf16* __restrict__ A,
-                                                        const __bf16* __restrict__ W,
-                                                        const float* __restrict__ bias,
-                                                        const float* __restrict__ R, void* __restrict__ Cv,
-                                                        uint32_t M, uint32_t N, uint32_t K, uint32_t ntn,
-                                                        uint64_t ldc) {
+// WM x WN waves, each owning MF x NF blocks of 32 x 32: tile = (32 MF WM) x (32 NF WN).
+//   <2,2,2,2>: 128 x 128, 256 threads, 64 KiB LDS, two workgroups per CU;
+//   <2,4,4,2>: 256 x 256, 512 threads, 128 KiB LDS, one per CU -- 128 x 64 per wave reads 6 operand
+//   fragments per 8 MFMAs instead of 4 per 4, and a slab byte feeds twice the flops.
+template <int ACT, bool RES, bool C16, int WM, int WN, int MF, int NF>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_tn_bf16_dma(const __bf16* __restrict__ A,
+                                                                 const __bf16* __restrict__ W,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ R,
+                                                                 void* __restrict__ Cv, uint32_t M, uint32_t N,
+                                                                 uint32_t K, uint32_t ntn, uint64_t ldc) {
+  constexpr uint32_t TM = 32 * MF * WM, TN = 32 * NF * WN, NW = WM * WN;
+  constexpr uint32_t ABYTES = TM * HBK * 2, WBYTES = TN * HBK * 2, BUF = ABYTES + WBYTES;
+  constexpr int NIA = TM * 8 / (64 * NW), NIW = TN * 8 / (64 * NW);  // DMA instructions per wave and slab
   float* C = reinterpret_cast<float*>(Cv);
   __bf16* Ch = reinterpret_cast<__bf16*>(Cv);
-  // [buffer][A | W][128 rows][64 bf16]
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 2 * BM * HBK * 2];
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // [2][A slab | W slab]
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware, bijective remap of the linear workgroup id (8 XCDs, round-robin dispatch)
   const uint32_t nwg = gridDim.x, orig = blockIdx.x;
   const uint32_t q8 = nwg / 8, r8 = nwg % 8, xcd = orig % 8;
   const uint32_t wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + orig / 8;
-  // grouped order inside an XCD's range: the ~64 workgroups resident on an XCD (32 CUs x 2) cover
-  // 8 row tiles x 8 column tiles, whose A and W slabs (3 MiB at K = 768) stay in its 4 MiB L2
+  // grouped order inside an XCD's range: the workgroups resident on an XCD together cover 8 row
+  // tiles x a few column tiles, whose current A and W slabs stay in its 4 MiB L2
   const uint32_t ntm = nwg / ntn;
   constexpr uint32_t GM = 8;
   const uint32_t group = wgid / (GM * ntn), in_group = wgid % (GM * ntn);
   const uint32_t gm = ntm - group * GM < GM ? ntm - group * GM : GM;
-  const uint64_t m0 = (uint64_t)(group * GM + in_group % gm) * BM, n0 = (uint64_t)(in_group / gm) * BN;
-  const uint32_t wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  floatx16 acc[2][2];
+  const uint64_t m0 = (uint64_t)(group * GM + in_group % gm) * TM, n0 = (uint64_t)(in_group / gm) * TN;
+  const uint32_t wm = (wave / WN) * (32 * MF), wn = (wave % WN) * (32 * NF);
+  floatx16 acc[MF][NF];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MF; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NF; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  // staging: instruction i of wave w fills LDS chunks [(4 i + w) * 64, + 64) of a 16 KiB image;
+  // staging: instruction i of wave w fills LDS chunks [(NW i + w) * 64, + 64) of a slab image;
   // chunk = (row, c) with row = chunk / 8
-  const __bf16* asrc[4];
-  const __bf16* wsrc[4];
+  const __bf16* asrc[NIA];
+  const __bf16* wsrc[NIW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const uint32_t chunk = (4u * i + wave) * 64u + lane, row = chunk >> 3, c = (chunk & 7u) ^ (row & 7u);
+  for (int i = 0; i < NIA; ++i) {
+    const uint32_t chunk = (NW * i + wave) * 64u + lane, row = chunk >> 3, c = (chunk & 7u) ^ ((row >> 1) & 7u);
     const uint64_t ra = m0 + row < M ? m0 + row : (uint64_t)M - 1;
-    const uint64_t rw = n0 + row < N ? n0 + row : (uint64_t)N - 1;
     asrc[i] = A + ra * K + c * 8u;
+  }
+#pragma unroll
+  for (int i = 0; i < NIW; ++i) {
+    const uint32_t chunk = (NW * i + wave) * 64u + lane, row = chunk >> 3, c = (chunk & 7u) ^ ((row >> 1) & 7u);
+    const uint64_t rw = n0 + row < N ? n0 + row : (uint64_t)N - 1;
     wsrc[i] = W + rw * K + c * 8u;
   }
   auto issue = [&](uint32_t k0, uint32_t buf) {
-    unsigned char* ab = lds + buf * (2 * BM * HBK * 2);
-    unsigned char* wb = ab + BM * HBK * 2;
+    unsigned char* ab = lds + buf * BUF;
+    unsigned char* wb = ab + ABYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t off = (4u * i + wave) * 1024u;  // wave-uniform destination, lanes follow linearly
-      __builtin_amdgcn_global_load_lds((isl_glb_void*)(asrc[i] + k0), (isl_lds_void*)(ab + off), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((isl_glb_void*)(wsrc[i] + k0), (isl_lds_void*)(wb + off), 16, 0, 0);
-    }
+    for (int i = 0; i < NIA; ++i)  // wave-uniform destination, lanes follow linearly
+      __builtin_amdgcn_global_load_lds((isl_glb_void*)(asrc[i] + k0), (isl_lds_void*)(ab + (NW * i + wave) * 1024u), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NIW; ++i)
+      __builtin_amdgcn_global_load_lds((isl_glb_void*)(wsrc[i] + k0), (isl_lds_void*)(wb + (NW * i + wave) * 1024u), 16, 0, 0);
   };
   const uint32_t kh = lane >> 5, c32 = lane & 31;
   const uint32_t nk = K / HBK;
@@ -221,27 +232,30 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_dma(const __bf16* __restrict
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of slab kt has landed
     __syncthreads();  // everyone's share has; everyone is done reading the other buffer
     if (kt + 1 < nk) issue((kt + 1) * HBK, (kt + 1) & 1);
-    const unsigned char* ab = lds + (kt & 1) * (2 * BM * HBK * 2);
-    const unsigned char* wb = ab + BM * HBK * 2;
+    const unsigned char* ab = lds + (kt & 1) * BUF;
+    const unsigned char* wb = ab + ABYTES;
 #pragma unroll
     for (int ks = 0; ks < HBK / 16; ++ks) {
       const uint32_t cl = 2 * ks + kh;  // logical 16-byte chunk of the row
-      const uint32_t rb0 = wn + c32, rb1 = wn + 32 + c32;
-      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wb + rb0 * 128u + ((cl ^ (rb0 & 7u)) << 4));
-      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wb + rb1 * 128u + ((cl ^ (rb1 & 7u)) << 4));
+      bf16x8 b[NF];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int j = 0; j < NF; ++j) {
+        const uint32_t rb = wn + 32 * j + c32;
+        b[j] = *reinterpret_cast<const bf16x8*>(wb + rb * 128u + ((cl ^ ((rb >> 1) & 7u)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MF; ++i) {
         const uint32_t ra = wm + 32 * i + c32;
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ab + ra * 128u + ((cl ^ (ra & 7u)) << 4));
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[i][1], 0, 0, 0);
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ab + ra * 128u + ((cl ^ ((ra >> 1) & 7u)) << 4));
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[i][j], 0, 0, 0);
       }
     }
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MF; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NF; ++j) {
       const uint64_t n = n0 + wn + j * 32 + c32;
       if (n >= N) continue;
       const float bv = bias ? bias[n] : 0.0f;
@@ -270,6 +284,32 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_dma(const __bf16* __restrict
     }
 }
 
+// Picks the tile by the size of the problem: the 256 x 256 tile needs enough tiles to fill the chip.
+template <int ACT, bool RES, bool C16>
+void launch_gemm_bf16_dma(const __bf16* A, const __bf16* W, const float* bias, const float* R, void* C,
+                          uint64_t M, uint64_t N, uint64_t K, uint64_t ldc, hipStream_t st) {
+  static const int tile_env = [] { const char* e = getenv("ISL_GEMM_TILE"); return e ? atoi(e) : 0; }();  // 128 / 256: A/B switch
+  const uint64_t big = ((M + 255) / 256) * ((N + 255) / 256);
+  const bool use_big = tile_env == 256 || (tile_env != 128 && big >= 512);
+  if (use_big) {
+    auto kern = gemm_tn_bf16_dma<ACT, RES, C16, 2, 4, 4, 2>;
+    constexpr size_t lds = 2 * (256 + 256) * HBK * 2;
+    static const bool once = [&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL(kern, dim3((uint32_t)big), dim3(512), lds, st, A, W, bias, R, C, (uint32_t)M, (uint32_t)N,
+                       (uint32_t)K, (uint32_t)((N + 255) / 256), ldc);
+  } else {
+    const uint64_t ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
+    auto kern = gemm_tn_bf16_dma<ACT, RES, C16, 2, 2, 2, 2>;
+    constexpr size_t lds = 2 * (BM + BN) * HBK * 2;
+    hipLaunchKernelGGL(kern, dim3((uint32_t)(ntm * ntn)), dim3(256), lds, st, A, W, bias, R, C, (uint32_t)M,
+                       (uint32_t)N, (uint32_t)K, (uint32_t)ntn, ldc);
+  }
+}
+
 template <int ACT, bool RES, bool A16, bool C16>
 void launch_gemm_bf16(const void* A, const __bf16* W, const float* bias, const float* R, void* C,
                       uint64_t M, uint64_t N, uint64_t K, hipStream_t st) {
@@ -279,9 +319,7 @@ void launch_gemm_bf16(const void* A, const __bf16* W, const float* bias, const f
   if constexpr (A16) {
     const uint64_t ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     if (!no_dma && K % HBK == 0 && ntm * ntn < 0x7FFFFFFFull && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0) {
-      hipLaunchKernelGGL((gemm_tn_bf16_dma<ACT, RES, C16>), dim3((uint32_t)(ntm * ntn)), dim3(256), 0, st,
-                         (const __bf16*)A, W, bias, R, C, (uint32_t)M, (uint32_t)N, (uint32_t)K, (uint32_t)ntn,
-                         (uint64_t)N);
+      launch_gemm_bf16_dma<ACT, RES, C16>((const __bf16*)A, W, bias, R, C, M, N, K, N, st);
       return;
     }
   }
@@ -294,9 +332,7 @@ void launch_gemm_bf16(const void* A, const __bf16* W, const float* bias, const f
 template <int EPI>
 void launch_gemm_bf16_distance(const __bf16* Q, const __bf16* Rows, const float* row_norm2, const float* q_norm2,
                                float* out, uint64_t M, uint64_t N, uint64_t K, uint64_t ldc, hipStream_t st) {
-  const uint64_t ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_tn_bf16_dma<EPI, false, false>), dim3((uint32_t)(ntm * ntn)), dim3(256), 0, st, Q, Rows,
-                     row_norm2, q_norm2, out, (uint32_t)M, (uint32_t)N, (uint32_t)K, (uint32_t)ntn, ldc);
+  launch_gemm_bf16_dma<EPI, false, false>(Q, Rows, row_norm2, q_norm2, out, M, N, K, ldc, st);
 }
 
 static __global__ void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, uint64_t n) {
