@@ -380,6 +380,11 @@ isl_status isl_hnsw_from_layers(uint64_t m, uint64_t m0, uint64_t ef_constructio
                                 const uint64_t* const* layer_neighbors, const uint64_t* levels,
                                 int32_t has_entry, uint64_t entry_point, uint64_t max_level,
                                 const float* vectors, int32_t device, isl_hnsw** out);
+/* HnswGraph::from_bytes, hnsw.rs:511-514: reads the bincode image of a HnswGraph (1.x default
+ * layout; HashMap entries in any order, node ids 0..n-1) and makes it resident on `device`.
+ * Truncated or inconsistent input -> ISL_ERR_DESERIALIZATION.  No writer: HashMap order makes the
+ * reference's own bytes non-deterministic. */
+isl_status isl_hnsw_from_bytes(const uint8_t* bytes, size_t len, int32_t device, isl_hnsw** out);
 void isl_hnsw_free(isl_hnsw* h);
 uint64_t isl_hnsw_len(const isl_hnsw* h);
 /* HnswGraph::search (hnsw.rs:458-504) for a batch of queries: greedy descent through layers

@@ -715,6 +715,19 @@ class HnswGraph:
     def is_empty(self) -> bool:
         return len(self) == 0
 
+    @classmethod
+    def from_bytes(cls, data: bytes, device: int = 0) -> "HnswGraph":
+        """HnswGraph::from_bytes (hnsw.rs:511-514): the bincode image of a HnswGraph."""
+        g = cls.__new__(cls)
+        buf = np.frombuffer(data, dtype=np.uint8)
+        h = C.c_void_p()
+        _check(_ffi.lib().isl_hnsw_from_bytes(_ptr(buf) if buf.size else None, buf.size, device,
+                                              C.byref(h)))
+        g._h = h
+        g._keep = None
+        g.vectors = None
+        return g
+
     def last_stats(self) -> dict:
         s = SearchStatsC()
         _check(_ffi.lib().isl_hnsw_last_stats(self._h, C.byref(s)))

@@ -86,6 +86,7 @@ SIGNATURES = {
     "isl_set_embeddings": (i32, [C.c_void_p, C.c_void_p, u64, u64, i32, i32]),
     "isl_search_batch": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64, C.c_void_p,
                                C.c_void_p, C.c_void_p]),
+    "isl_hnsw_from_bytes": (i32, [C.c_void_p, C.c_size_t, i32, P(C.c_void_p)]),
     "isl_distance_matrix_bf16": (i32, [i32, C.c_void_p, u64, C.c_void_p, u64, u64, C.c_void_p, i32, i32,
                                        C.c_void_p]),
     "isl_index_set_pq_codes": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, u64, i32]),

@@ -4,6 +4,7 @@
 // used), the upper layers are kept as device CSR arrays for the greedy descent.
 #include "common.hpp"
 
+#include <algorithm>
 #include <vector>
 
 struct isl_hnsw {
@@ -117,6 +118,93 @@ isl_status isl_hnsw_from_layers(uint64_t m, uint64_t m0, uint64_t ef_constructio
   c->hnsw_layers = max_level + 1;
   *out = h;
   return ISL_OK;
+}
+
+// HnswGraph::from_bytes, hnsw.rs:511-514: bincode of the derive(Serialize) struct (hnsw.rs:150-164).
+// bincode 1.x default layout as in api_index.hip (little-endian, fixed-width, usize = u64, Vec and
+// HashMap = u64 length + items, Option = u8 tag, C-like enum = u32 variant index):
+//   config { m, m0, ef_construction: u64; ml: f64; metric: u32; max_layers: u64 }          hnsw.rs:15-28
+//   nodes: u64 count, then (key: u64, HnswNode { id: u64; vector: Vec<f32>; connections:
+//          Vec<Vec<u64>>; level: u64 }) in the writer's HashMap order                      hnsw.rs:90-99
+//   entry_point: Option<u64>; max_level: u64; dimension: Option<u64>; next_id: u64
+// The byte layout is unpinned by the reference (tests round-trip only, hnsw.rs:689-709) and the
+// pinned bincode is 3.0.0 (Cargo.lock:838-841); this is the documented 1.x-compatible intent.
+// Node ids must be 0..n-1 (insert assigns them from next_id, hnsw.rs:218-219), in any order.
+isl_status isl_hnsw_from_bytes(const uint8_t* bytes, size_t len, int32_t device, isl_hnsw** out) {
+  if (!out || (!bytes && len)) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL argument");
+  size_t pos = 0;
+  bool ok = true;
+  auto need = [&](size_t n) { if (ok && len - pos < n) ok = false; return ok; };
+  auto u64 = [&]() -> uint64_t { uint64_t v = 0; if (need(8)) { memcpy(&v, bytes + pos, 8); pos += 8; } return v; };
+  auto u32 = [&]() -> uint32_t { uint32_t v = 0; if (need(4)) { memcpy(&v, bytes + pos, 4); pos += 4; } return v; };
+  auto u8 = [&]() -> uint8_t { uint8_t v = 0; if (need(1)) { v = bytes[pos]; pos += 1; } return v; };
+  auto bad = [&](const char* what) {
+    return isl::fail(ISL_ERR_DESERIALIZATION, "Deserialization error: %s (offset %llu of %llu)", what,
+                     (unsigned long long)pos, (unsigned long long)len);
+  };
+  const uint64_t m = u64(), m0 = u64(), efc = u64();
+  (void)u64();  // ml: f64, only used by random_level (hnsw.rs:196-200)
+  const uint32_t metric = u32();
+  (void)u64();  // max_layers
+  const uint64_t n = u64();
+  if (!ok) return bad("truncated header");
+  if (metric > ISL_METRIC_MANHATTAN) return bad("unknown DistanceMetric variant");
+  if (n > (len - pos) / 32) return bad("node count exceeds the buffer");  // >= 32 bytes per node
+  std::vector<uint64_t> levels(n, 0);
+  std::vector<float> vectors;
+  std::vector<uint8_t> seen(n, 0);
+  std::vector<std::vector<std::vector<uint64_t>>> conn(n);
+  uint64_t d = 0;
+  for (uint64_t e = 0; e < n && ok; ++e) {
+    const uint64_t key = u64(), id = u64(), vlen = u64();
+    if (!ok) break;
+    if (key != id) return bad("HashMap key differs from HnswNode::id");
+    if (id >= n || seen[id]) return isl::fail(ISL_ERR_UNSUPPORTED, "HnswGraph node ids must be 0..n-1 (id %llu of %llu nodes)",
+                                              (unsigned long long)id, (unsigned long long)n);
+    seen[id] = 1;
+    if (e == 0) { d = vlen; vectors.assign((size_t)n * d, 0.0f); }
+    if (vlen != d) return bad("nodes with different vector lengths");
+    if (!need(vlen * 4)) break;
+    memcpy(vectors.data() + (size_t)id * d, bytes + pos, vlen * 4);
+    pos += vlen * 4;
+    const uint64_t nl = u64();
+    if (!ok || nl > (len - pos) / 8 + 1) { ok = false; break; }
+    conn[id].resize(nl);
+    for (uint64_t L = 0; L < nl && ok; ++L) {
+      const uint64_t c = u64();
+      if (!ok || c > (len - pos) / 8) { ok = false; break; }
+      conn[id][L].resize(c);
+      if (c) memcpy(conn[id][L].data(), bytes + pos, c * 8);
+      pos += c * 8;
+    }
+    levels[id] = u64();
+  }
+  const uint8_t has_entry = u8();
+  const uint64_t entry = has_entry ? u64() : 0;
+  const uint64_t max_level = u64();
+  const uint8_t has_dim = u8();
+  const uint64_t dim = has_dim ? u64() : 0;
+  (void)u64();  // next_id
+  if (!ok) return bad("truncated input");
+  if (has_entry > 1 || has_dim > 1) return bad("invalid Option tag");
+  if (pos != len) return bad("trailing bytes");
+  if (n && has_dim && dim != d) return bad("dimension differs from the node vectors");
+  // per-layer CSR over all nodes
+  uint64_t num_layers = max_level + 1;
+  for (uint64_t i = 0; i < n; ++i) num_layers = std::max<uint64_t>(num_layers, conn[i].size());
+  if (num_layers > 64) return bad("implausible layer count");
+  std::vector<std::vector<uint64_t>> offs(num_layers, std::vector<uint64_t>(n + 1, 0)), adjs(num_layers);
+  for (uint64_t L = 0; L < num_layers; ++L) {
+    for (uint64_t i = 0; i < n; ++i) {
+      if (L < conn[i].size()) adjs[L].insert(adjs[L].end(), conn[i][L].begin(), conn[i][L].end());
+      offs[L][i + 1] = adjs[L].size();
+    }
+    if (adjs[L].empty()) adjs[L].push_back(0);
+  }
+  std::vector<const uint64_t*> po(num_layers), pa(num_layers);
+  for (uint64_t L = 0; L < num_layers; ++L) { po[L] = offs[L].data(); pa[L] = adjs[L].data(); }
+  return isl_hnsw_from_layers(m, m0, efc, (int32_t)metric, n, n ? d : dim, num_layers, po.data(), pa.data(),
+                              levels.data(), has_entry, entry, max_level, vectors.data(), device, out);
 }
 
 isl_status isl_hnsw_search_batch(const isl_hnsw* h, const float* queries, uint64_t nq, uint64_t d,
