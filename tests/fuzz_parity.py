@@ -141,16 +141,77 @@ def build_case(rng, case):
     return {"exact_path": 0, "replayed": 0}
 
 
+def two_level_case(rng, case):
+    """Two-level search (extension): random graphs, vectors, PQ shapes, ratios -- window sizes,
+    merge batch sizes and ties all over the place -- against orc_two_level_search."""
+    from test_two_level_cpu import make_pq
+    n = int(rng.choice([40, 300, 1200, 3000]))
+    m, dsub = int(rng.choice([1, 2, 4, 8, 16])), int(rng.choice([1, 3, 8]))
+    d = m * dsub
+    seed = int(rng.integers(1 << 30))
+    vec = clustered_vectors(n, d, seed) if rng.random() < 0.5 else uniform_vectors(n, d, seed)
+    quant = rng.random()
+    if quant < 0.3:
+        vec = np.round(vec * 2) / 2
+        vec[np.abs(vec).sum(1) == 0, 0] = 1.0
+    elif quant < 0.4:
+        vec[n // 2:] = vec[:n - n // 2]
+    vec = vec.astype(np.float32)
+    deg = int(rng.choice([4, 12, 30, 64, 100]))
+    if rng.random() < 0.5 and n >= 128 and deg <= 64:
+        off, nb = knn_graph(vec, min(deg, n - 1), seed)
+    else:
+        off, nb = random_csr(n, min(deg, n - 1), seed, dup=rng.random() < 0.2)
+    K = int(rng.choice([2, 7, 16, 64]))
+    cb, codes = make_pq(vec, m, min(K, n), seed % 1000)
+    metric = int(rng.integers(0, 4))
+    ef = int(rng.choice([1, 2, 7, 33, 64, 128, 200, 300]))
+    k = int(rng.choice([1, 3, 10, 50]))
+    ratio = float(rng.choice([0.01, 0.1, 0.25, 0.5, 1.0, 0.0]))
+    entry = int(rng.integers(0, n))
+    nq = 16
+    q = (vec[rng.integers(0, n, nq)] + (rng.random((nq, d), dtype=np.float32) - 0.5) *
+         np.float32(rng.choice([0.0, 0.05, 0.5]))).astype(np.float32)
+    levels = np.zeros(n, np.uint64)
+    degs = (off[1:] - off[:-1]).astype(np.uint64)
+    csr = orc.Csr(node_offsets=off, neighbors=nb, levels=levels, entry_point=entry, max_level=0,
+                  degree_counts=degs)
+    g = ia.CsrGraph(node_offsets=off, neighbors=nb, levels=levels, entry_point=entry, max_level=0,
+                    num_nodes=n, degree_counts=degs)
+    idx = ia.LeannIndex.from_csr(g, ia.LeannConfig(metric=ia.DistanceMetric(metric)), dimension=d)
+    idx.upload(0)
+    idx.set_embeddings(vec)
+    pq = ia.ProductQuantizer(d, cb)
+    idx.set_pq_codes(pq, codes)
+    ids, dist, cnt = idx.search_two_level_batch(q, k, ef, ratio)
+    st = idx.last_stats()
+    tot = {"expansions": 0, "evals": 0, "pushes": 0}
+    desc = f"case {case}: n={n} d={d} m={m} K={K} deg={deg} metric={metric} ef={ef} k={k} a={ratio} quant={quant:.2f}"
+    for i in range(nq):
+        r = orc.two_level_search(csr, vec, cb, codes, q[i], k, ef, ratio, metric=metric)
+        assert r.status == 0, desc
+        c = int(cnt[i])
+        assert c == r.ids.size, (desc, i, c, r.ids.size)
+        assert ids[i, :c].tolist() == r.ids.tolist(), (desc, i, ids[i, :c], r.ids)
+        assert bits(dist[i, :c]).tolist() == bits(r.dist).tolist(), (desc, i)
+        for f in tot:
+            tot[f] += r.counters[f]
+    for f in tot:
+        assert st[f] == tot[f], (desc, f, st[f], tot[f])
+    del pq
+    return {"exact_path": 0, "replayed": 0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--mode", choices=["leann", "hnsw", "build"], default="leann")
+    ap.add_argument("--mode", choices=["leann", "hnsw", "build", "two_level"], default="leann")
     args = ap.parse_args()
     orc.build()
     rng = np.random.default_rng(args.seed)
     t0, case, exact, replay = time.time(), 0, 0, 0
-    fn = {"leann": one_case, "hnsw": hnsw_case, "build": build_case}[args.mode]
+    fn = {"leann": one_case, "hnsw": hnsw_case, "build": build_case, "two_level": two_level_case}[args.mode]
     while time.time() - t0 < args.seconds:
         st = fn(rng, case)
         exact += st["exact_path"]

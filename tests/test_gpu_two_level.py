@@ -213,3 +213,12 @@ def test_two_level_config5_shape(orc):
     q = clustered_vectors(6, d, 82, per_cluster=35)
     assert_same(orc, idx, csr, vw, cb, codes, q, 10, 48, 0.25)
     del pq
+
+
+def test_two_level_fuzz_slice(orc):
+    """A fixed slice of tests/fuzz_parity.py --mode two_level (random graphs, PQ shapes, ratios,
+    ef / k, quantised and duplicated rows); the tool itself runs for minutes on the GPU box."""
+    import fuzz_parity
+    rng = np.random.default_rng(2027)
+    for case in range(25):
+        fuzz_parity.two_level_case(rng, case)

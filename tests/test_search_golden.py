@@ -72,3 +72,49 @@ def test_hip_path_returns_the_golden_vectors():
     for i in range(q.shape[0]):
         assert got[i][0].tolist() == z["hnsw_ids"][i].tolist()
         assert got[i][1].view(np.uint32).tolist() == z["hnsw_dist"][i].view(np.uint32).tolist()
+
+
+# ---- two-level search (extension): tests/golden/two_level_small.npz, make_two_level_golden.py ----
+GOLD2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "two_level_small.npz")
+CASES2 = ((10, 32, 0.1), (5, 5, 0.5), (10, 64, 0.25), (10, 48, 1.0))
+
+
+def test_oracle_still_reproduces_the_two_level_golden_vectors(orc):
+    z, z2 = np.load(GOLD), np.load(GOLD2)
+    rows, q = z["rows"], z["queries"]
+    for metric in range(4):
+        csr = orc.Csr(z[f"m{metric}_offsets"], z[f"m{metric}_neighbors"], entry_point=int(z[f"m{metric}_entry"]))
+        for (k, ef, a) in CASES2:
+            t = f"m{metric}_k{k}_ef{ef}_a{int(a * 100)}"
+            for i in range(q.shape[0]):
+                r = orc.two_level_search(csr, rows, z2["codebooks"], z2["codes"], q[i], k, ef, a, metric=metric)
+                c = int(z2[t + "_cnt"][i])
+                assert r.ids.tolist() == z2[t + "_ids"][i, :c].tolist()
+                assert r.dist.view(np.uint32).tolist() == z2[t + "_dist"][i, :c].view(np.uint32).tolist()
+                assert [r.counters[f] for f in ("expansions", "edges", "evals", "pushes")] == z2[t + "_ctr"][i].tolist()
+
+
+@pytest.mark.gpu
+def test_hip_path_returns_the_two_level_golden_vectors():
+    import islands_amd as ia
+    z, z2 = np.load(GOLD), np.load(GOLD2)
+    rows, q, levels = z["rows"], z["queries"], z["levels"]
+    n = rows.shape[0]
+    pq = ia.ProductQuantizer(rows.shape[1], z2["codebooks"])
+    for metric in range(4):
+        off, nb = z[f"m{metric}_offsets"], z[f"m{metric}_neighbors"]
+        g = ia.CsrGraph(node_offsets=off, neighbors=nb, levels=levels, entry_point=int(z[f"m{metric}_entry"]),
+                        max_level=int(z[f"m{metric}_max_level"]), num_nodes=n,
+                        degree_counts=(off[1:] - off[:-1]).astype(np.uint64))
+        idx = ia.LeannIndex.from_csr(g, ia.LeannConfig(metric=ia.DistanceMetric(metric)), dimension=rows.shape[1])
+        idx.upload(0)
+        idx.set_embeddings(rows)
+        idx.set_pq_codes(pq, z2["codes"])
+        for (k, ef, a) in CASES2:
+            ids, dist, cnt = idx.search_two_level_batch(q, k, ef, a)
+            t = f"m{metric}_k{k}_ef{ef}_a{int(a * 100)}"
+            assert cnt.tolist() == z2[t + "_cnt"].tolist()
+            for i in range(q.shape[0]):
+                c = int(cnt[i])
+                assert ids[i, :c].tolist() == z2[t + "_ids"][i, :c].tolist(), (t, i)
+                assert dist[i, :c].view(np.uint32).tolist() == z2[t + "_dist"][i, :c].view(np.uint32).tolist()
