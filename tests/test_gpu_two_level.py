@@ -222,3 +222,20 @@ def test_two_level_fuzz_slice(orc):
     rng = np.random.default_rng(2027)
     for case in range(25):
         fuzz_parity.two_level_case(rng, case)
+
+
+def test_two_level_many_queries_and_large_ef(orc):
+    """More queries than resident waves (the kernel's work queue hands a slot several queries, the
+    per-slot state must be clean each time), ef beyond 512 and k beyond ef."""
+    n, d, m, K = 2500, 32, 8, 32
+    v = clustered_vectors(n, d, 91)
+    off, nb = knn_graph(v, 24, seed=7)
+    cb, codes = make_pq(v, m, K, 15)
+    csr = orc.Csr(off, nb, entry_point=2)
+    idx = make_index(csr, v)
+    pq = attach_pq(idx, cb, codes)
+    q = clustered_vectors(4000, d, 92)
+    assert_same(orc, idx, csr, v, cb, codes, q, 5, 24, 0.3)
+    assert_same(orc, idx, csr, v, cb, codes, q[:12], 20, 600, 0.2)
+    assert_same(orc, idx, csr, v, cb, codes, q[:12], 700, 16, 0.5)     # ef = max(ef, k)
+    del pq
