@@ -255,6 +255,13 @@ class HnswGraph {
                                pa.data(), n ? levels.data() : nullptr, entry_point ? 1 : 0,
                                entry_point.value_or(0), max_level, n ? vectors.data() : nullptr, device, &h_));
   }
+  // HnswGraph::from_bytes, hnsw.rs:511-514 (bincode image; entries in any HashMap order)
+  static HnswGraph from_bytes(const std::vector<uint8_t>& bytes, int32_t device = 0) {
+    HnswGraph g;
+    check(isl_hnsw_from_bytes(bytes.data(), bytes.size(), device, &g.h_));
+    return g;
+  }
+  HnswGraph(HnswGraph&& o) noexcept : h_(o.h_), vectors_(std::move(o.vectors_)), dim_(o.dim_) { o.h_ = nullptr; }
   HnswGraph(const HnswGraph&) = delete;
   HnswGraph& operator=(const HnswGraph&) = delete;
   ~HnswGraph() { isl_hnsw_free(h_); }
@@ -277,11 +284,12 @@ class HnswGraph {
     return out;
   }
   std::optional<std::vector<float>> get_vector(uint64_t id) const {  // get_node(id).vector, hnsw.rs:507-510
-    if (id >= len()) return std::nullopt;
+    if (id >= len() || vectors_.empty()) return std::nullopt;  // a graph read by from_bytes keeps no host copy
     return std::vector<float>(vectors_.begin() + id * dim_, vectors_.begin() + (id + 1) * dim_);
   }
 
  private:
+  HnswGraph() = default;
   isl_hnsw* h_ = nullptr;
   std::vector<float> vectors_;
   uint64_t dim_ = 0;
