@@ -31,6 +31,28 @@ __global__ __launch_bounds__(64) void pq_tables_kernel(const float* __restrict__
   if ((uint32_t)lane < R) tables[((uint64_t)q * m + j) * K + c0 + lane] = v;
 }
 
+// Short subvectors (dsub <= 64, the usual case: 8 at d = 768 / m = 96, 64 at d = 4096 / m = 64): one
+// workgroup per (query, subquantizer), one thread per centroid walking its dsub elements in order
+// -- the same left fold, without the wave-tile machinery (a tenth of its time at dsub = 8).
+__global__ __launch_bounds__(256) void pq_tables_direct_kernel(const float* __restrict__ queries, uint32_t d,
+                                                              const float* __restrict__ cb, uint32_t m,
+                                                              uint32_t K, uint32_t dsub, uint32_t cstride,
+                                                              float* __restrict__ tables) {
+  __shared__ float qs[64];
+  const uint32_t j = blockIdx.x, q = blockIdx.y;
+  if (threadIdx.x < dsub) qs[threadIdx.x] = queries[(uint64_t)q * d + (uint64_t)j * dsub + threadIdx.x];
+  __syncthreads();
+  for (uint32_t c = threadIdx.x; c < K; c += 256) {
+    const float* row = cb + ((uint64_t)j * K + c) * cstride;
+    float s = 0.0f;
+    for (uint32_t i = 0; i < dsub; ++i) {
+      const float df = qs[i] - row[i];
+      s += df * df;  // (a - b).powi(2), summed left to right (pq.rs:326-331)
+    }
+    tables[((uint64_t)q * m + j) * K + c] = s;
+  }
+}
+
 // table_distance, pq.rs:341-348: sqrt(sum_j tables[j][code_j]), left fold over j.
 __global__ void pq_table_distance_kernel(const float* __restrict__ tables,
                                          const uint16_t* __restrict__ codes, uint64_t n, uint32_t m,
@@ -112,6 +134,12 @@ isl_status launch_tables(const isl_pq* pq, const float* d_queries, uint64_t nq, 
   uint32_t cblocks = (uint32_t)((pq->K + 63) / 64);
   for (uint64_t q0 = 0; q0 < nq; q0 += 65535) {
     uint32_t nb = (uint32_t)std::min<uint64_t>(65535, nq - q0);
+    if (pq->dsub <= 64) {
+      hipLaunchKernelGGL(pq_tables_direct_kernel, dim3((uint32_t)pq->m, nb), dim3(256), 0, st,
+                         d_queries + q0 * pq->dimension, (uint32_t)pq->dimension, pq->d_codebooks, (uint32_t)pq->m,
+                         (uint32_t)pq->K, (uint32_t)pq->dsub, (uint32_t)pq->cstride, d_tables + q0 * pq->m * pq->K);
+      continue;
+    }
     hipLaunchKernelGGL(pq_tables_kernel, dim3((uint32_t)pq->m * cblocks, nb), dim3(64), lds, st,
                        d_queries + q0 * pq->dimension, (uint32_t)pq->dimension, pq->d_codebooks,
                        (uint32_t)pq->m, (uint32_t)pq->K, (uint32_t)pq->dsub, (uint32_t)pq->cstride,
