@@ -197,13 +197,25 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* __restr
   const uint32_t q0 = blockIdx.y * 64;
   const float inv_scale = sqrtf((float)DH);
   constexpr int LPR = DH / 4;  // lanes per row when staging with float4 loads
-  auto stage = [&](float* T, uint32_t row0, uint32_t which) {  // rows row0.. of Q (0) / K (1) / V (2)
-    for (uint32_t rr = lane / LPR; rr < 64; rr += 64 / LPR) {
-      const uint32_t c = (lane % LPR) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + rr < L)
-        v = *reinterpret_cast<const float4*>(qkv + ((uint64_t)b * L + row0 + rr) * ld + which * h + hd * DH + c);
-      T[rr * LD + c] = v.x; T[rr * LD + c + 1] = v.y; T[rr * LD + c + 2] = v.z; T[rr * LD + c + 3] = v.w;
+  // Staging of 64 rows of Q (0) / K (1) / V (2) in two halves: all loads of the block are issued
+  // together (one memory round trip per stage instead of one per four rows), the LDS stores follow
+  // when the tile is free -- the V block is fetched while the scores are still being computed.
+  constexpr int RPI = 64 / LPR;  // rows per iteration
+  const uint32_t sc = (lane % LPR) * 4;
+  auto stage_load = [&](float4 (&v)[LPR], uint32_t row0, uint32_t which) {
+#pragma unroll
+    for (int it = 0; it < LPR; ++it) {
+      const uint32_t rr = lane / LPR + it * RPI;
+      const uint32_t row = row0 + rr < L ? row0 + rr : L - 1;  // clamped: the load stays unconditional
+      v[it] = *reinterpret_cast<const float4*>(qkv + ((uint64_t)b * L + row) * ld + which * h + hd * DH + sc);
+      if (row0 + rr >= L) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stage_store = [&](float* T, const float4 (&v)[LPR]) {
+#pragma unroll
+    for (int it = 0; it < LPR; ++it) {
+      const uint32_t rr = lane / LPR + it * RPI;
+      T[rr * LD + sc] = v[it].x; T[rr * LD + sc + 1] = v[it].y; T[rr * LD + sc + 2] = v[it].z; T[rr * LD + sc + 3] = v[it].w;
     }
   };
   floatx16 o[CF][2];
@@ -216,8 +228,15 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* __restr
   float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.0f, 0.0f};
   for (uint32_t j0 = 0; j0 < L; j0 += 64) {
     __syncthreads();
-    stage(Ta, q0, 0);
-    stage(Tb, j0, 1);
+    {
+      float4 vq[LPR], vk[LPR];
+      stage_load(vq, q0, 0);
+      stage_load(vk, j0, 1);
+      stage_store(Ta, vq);
+      stage_store(Tb, vk);
+    }
+    float4 vv[LPR];
+    stage_load(vv, j0, 2);  // in flight during the score MFMAs
     __syncthreads();
     // S^T[j][q] = sum_c K[j][c] Q[q][c]
     floatx16 sT[2][2];
@@ -237,7 +256,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* __restr
       sT[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, sT[1][1], 0, 0, 0);
     }
     __syncthreads();
-    stage(Ta, j0, 2);  // V block replaces the Q block
+    stage_store(Ta, vv);  // V block replaces the Q block
     // scores: scale, mask bias per key (row), keys past L excluded
     float cmax[2] = {-INFINITY, -INFINITY};
 #pragma unroll
