@@ -155,7 +155,8 @@ def main():
             out.copy_(torch.cat(parts, 0).to(out.device))
 
     import islands_amd as ia
-    from islands_amd import synth
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth  # the synthetic-workload harness (data, bench graph, ground truth): not product code
 
     N, d, nq, k, ef = args.nodes, args.dim, args.nq, args.k, args.ef
     def measure(mode):
@@ -191,7 +192,13 @@ def main():
             idx.set_embeddings_bf16(None, device_ptr=x16.data_ptr(), n=n_local, d=d)
         else:
             idx.set_embeddings(None, device_ptr=x.data_ptr(), n=n_local, d=d)
-        log(f"index resident in {time.time() - t0:.1f}s")
+        # every lane's buffers, the padded adjacency and the exact-kernel pool up front: nothing on
+        # the search path allocates or synchronises for set-up afterwards (isl_index_prepare), so
+        # the timed region does not depend on --warmup
+        depth = max(1, min(args.pipeline, 16))
+        idx.prepare(nq, ef, k, depth)
+        torch.cuda.synchronize()
+        log(f"index resident and {depth} search lanes prepared in {time.time() - t0:.1f}s")
 
         nb_batches = max(1, min(args.distinct_batches, args.steps + args.warmup))
         qsets, truths = [], []
@@ -204,7 +211,6 @@ def main():
             truths.append((ti + lo, td))
         torch.cuda.synchronize()
 
-        depth = max(1, min(args.pipeline, 16))
         # one output set per search in flight
         outs = [(torch.zeros((nq, k), dtype=torch.int64, device=dev),
                  torch.zeros((nq, k), dtype=torch.float32, device=dev),
@@ -241,8 +247,7 @@ def main():
                                                  o[1].data_ptr(), o[2].data_ptr())
 
         def finish(b, token):
-            idx.wait(token)
-            st = idx.last_stats()
+            st = idx.wait_stats(token)  # the counters of exactly this call
             o = outs[b % depth]
             if shard_mode:
                 # the one exchange step of the path: per-shard top-k over xGMI (RCCL all-gather)
@@ -268,7 +273,7 @@ def main():
         def run(first, count, collect):
             """Runs steps [first, first+count) with `depth` searches in flight."""
             agg = {"queries": 0, "expansions": 0, "edges": 0, "evals": 0, "pushes": 0,
-                   "exact_path": 0, "replayed": 0, "kernel_ms": 0.0}
+                   "exact_path": 0, "replayed": 0, "kernel_ms": 0.0, "allocations": 0}
             kept = []
             pending = []
             for s in range(first, first + count):
@@ -300,6 +305,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
 
+        ref_ids = {b: ids_b for (b, ids_b, cnt_b) in recalls} if not shard_mode else {}
         rec = []
         for (b, ids_b, cnt_b) in recalls:
             truth = g_truth[b] if shard_mode else truths[b][0]
@@ -312,18 +318,11 @@ def main():
         bytes_per_launch = algorithmic_bytes(agg, d, k, 2 if args.row_dtype == 'bf16' else 4) / max(args.steps, 1)
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         agg_gbs = algorithmic_bytes(agg, d, k, 2 if args.row_dtype == 'bf16' else 4) / elapsed / 1e9
-        # HBM bytes per launch come from a separate rocprofv3 --pmc FETCH_SIZE pass (counters cannot be
-        # read from inside this process); the committed measurement applies to the headline workload only
+        # HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE) cannot be read from inside this process;
+        # tools/measure_traffic.py runs this same configuration under the profiler and hands the
+        # figure over in ISL_TRAFFIC_BYTES.  Without it the field is null -- never a stored constant.
         traffic_env = os.environ.get("ISL_TRAFFIC_BYTES")
-        traffic_src = None
-        if (not traffic_env and world == 1 and args.row_dtype == 'f32'
-                and (N, d, nq, ef, k) == (10_000_000, 768, 1024, 128, 10)):
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch.json")) as fh:
-                    traffic_env = str(json.load(fh)["search"]["hbm_bytes_per_launch"])
-                    traffic_src = "profiles/r01_pmc_fetch.json (rocprofv3 --pmc FETCH_SIZE x 1024 x 2)"
-            except (OSError, KeyError, ValueError):
-                traffic_env = None
+        traffic_src = os.environ.get("ISL_TRAFFIC_SOURCE") if traffic_env else None
 
         result = {
             "metric": "queries/sec @ recall@10>=0.95, 10Mx768 ef=128",
@@ -352,6 +351,7 @@ def main():
                               "edges": round(agg["edges"] / max(agg["queries"], 1), 1),
                               "evals": round(agg["evals"] / max(agg["queries"], 1), 1)},
                 "exact_path_queries": agg["exact_path"], "replayed_queries": agg["replayed"],
+                "allocations_in_timed_region": agg["allocations"],
             },
             "roofline": {
                 # `depth` launches of the search kernel overlap on the chip; the chip-level figure is
@@ -370,17 +370,42 @@ def main():
             },
         }
         if world == 1:
-            # the boundary also takes host buffers (isl_search_batch): PCIe both ways, one
-            # synchronous call at a time -- reported for context, never the headline value
-            qh = qsets[0].cpu().numpy()
-            idx.search_batch(qh, k, ef)
+            # QPS by SURVEY 8(d): host buffers in, host buffers out (the caller contract of
+            # search.rs:150-181 / indexer/service.rs:781-785), `depth` calls in flight through
+            # isl_search_batch_async -- H2D of the queries and D2H of the answers inside the timed
+            # region, pageable numpy arrays on both sides.  Reported next to the headline, which the
+            # bench contract defines on HBM-resident inputs.
+            qh = [q.cpu().numpy() for q in qsets]
+            houts = [(np.zeros((nq, k), np.uint64), np.zeros((nq, k), np.float32), np.zeros(nq, np.uint32))
+                     for _ in range(depth)]
+
+            def host_run(first, count):
+                pend, allocs = [], 0
+                for s_ in range(first, first + count):
+                    pend.append(idx.search_batch_async(qh[s_ % nb_batches], k, ef, out=houts[s_ % depth]))
+                    if len(pend) >= depth:
+                        allocs += idx.wait_stats(pend.pop(0))["allocations"]
+                while pend:
+                    allocs += idx.wait_stats(pend.pop(0))["allocations"]
+                return allocs
+
+            host_run(0, min(args.warmup, 2))
+            torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(5):
-                idx.search_batch(qh, k, ef)
+            hall = host_run(0, args.steps)
+            torch.cuda.synchronize()
             dt = time.perf_counter() - t1
-            result["host_pointer_path"] = {
-                "value": round(5 * nq / dt, 2), "unit": "queries/s", "ms_per_call": round(dt / 5 * 1e3, 3),
-                "note": "isl_search_batch with host query/result buffers, synchronous calls (PCIe included)"}
+            ref = ref_ids.get((args.steps - 1) % nb_batches)
+            same = (bool((torch.from_numpy(houts[(args.steps - 1) % depth][0].astype(np.int64)).to(dev) == ref)
+                         .all().item()) if ref is not None else None)
+            result["host_buffer_path"] = {
+                "value": round(args.steps * nq / dt, 2), "unit": "queries/s",
+                "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "ratio_to_device_resident": round((args.steps * nq / dt) / value, 4),
+                "calls_in_flight": depth, "allocations": hall,
+                "ids_equal_device_resident_path": same,
+                "note": "isl_search_batch_async: pageable host queries in, pageable host results out, "
+                        "PCIe both ways inside the timed region (SURVEY 8d's QPS definition)"}
         return result, (x, offsets, neighbours, entry, qsets)
 
     result, (x, offsets, neighbours, entry, qsets) = measure(args.mode)

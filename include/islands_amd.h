@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISL_ABI_VERSION 1
+#define ISL_ABI_VERSION 2
 
 typedef int32_t isl_status;
 
@@ -186,16 +186,55 @@ isl_status isl_set_embeddings(isl_index* idx, const void* rows, uint64_t n, uint
                               int32_t dtype, int32_t mem);
 
 /* ---- search ---- */
+/* Work counters of one search call (summed over the batch): the inputs of the roofline formula
+ * (SURVEY.md section 8d). */
+typedef struct isl_search_stats {
+  uint64_t queries;
+  uint64_t expansions;     /* H: candidates expanded */
+  uint64_t edges;          /* E: neighbour ids read */
+  uint64_t evals;          /* V: embeddings fetched / distances evaluated */
+  uint64_t pushes;         /* heap insertions */
+  uint64_t exact_path;     /* queries answered by the heap-exact kernel */
+  uint64_t replayed;       /* queries whose tied prefix was re-ordered by the replay kernel */
+  double kernel_ms;        /* HIP-event time of the search kernels of that call */
+  uint64_t encoded_nodes;    /* recompute provider: embeddings computed by the encoder */
+  uint64_t recompute_rounds; /* recompute provider: search rounds of that call (0 otherwise) */
+  uint64_t allocations;    /* device / pinned-host allocations and stream / event creations the
+                              call had to make (0 for every call that fits isl_index_prepare) */
+} isl_search_stats;
+
+/* Sets up everything a search needs so that no later call allocates, creates a stream or
+ * synchronises for set-up: `lanes` (1..16) search lanes sized for batches of up to max_nq queries
+ * with ef <= max_ef and k <= max_k (streams, events, per-query arrays, overflow tables, push
+ * logs, pinned staging buffers for the host-pointer entry points), the padded adjacency, the
+ * shared scratch pool of the heap-exact kernel, and one empty launch of the search kernels on
+ * every lane's stream (code objects loaded, hardware queues created).  Call it after
+ * isl_index_upload + a provider setter.  The reference has no such step (its search allocates
+ * per call, leann.rs:903-908); without it the first calls on each lane do this work lazily and
+ * report it in isl_search_stats::allocations. */
+isl_status isl_index_prepare(isl_index* idx, uint64_t max_nq, uint64_t max_ef, uint64_t max_k,
+                             int32_t lanes);
+
 /* LeannIndex::search_with_params over a batch of queries (leann.rs:868-896;
  * batch = Searcher::search_batch semantics, search.rs:179-181: each query is
  * answered independently, results in query order).
  *   queries: nq rows of d floats; out_ids/out_dist: nq*k slots, row i holds
  *   out_count[i] <= k valid entries, ascending distance.
  * Errors that the reference raises per query (NodeNotFound) fail the whole
- * call with the first failing query's error, as the sequential map would. */
+ * call with the first failing query's error, as the sequential map would.
+ * Host buffers in, host buffers out (the caller contract of search.rs:150-181,
+ * indexer/service.rs:781-785); re-entrant: concurrent calls run on different lanes. */
 isl_status isl_search_batch(const isl_index* idx, const float* queries, uint64_t nq, uint64_t d,
                             uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dist,
                             uint32_t* out_count);
+/* Pipelined form of isl_search_batch: copies `queries` into the lane's pinned staging buffer
+ * (they may be reused as soon as the call returns), enqueues H2D copy, search and D2H copies on
+ * the lane's stream and returns.  out_ids / out_dist / out_count must stay valid until
+ * isl_search_wait[_stats](*token) has returned; they are written there.  Up to 16 calls may be
+ * in flight.  token 0 = answered immediately (empty index, nq == 0). */
+isl_status isl_search_batch_async(const isl_index* idx, const float* queries, uint64_t nq, uint64_t d,
+                                  uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dist,
+                                  uint32_t* out_count, uint64_t* token);
 /* Same with every buffer already on the index's device; enqueued on `stream`
  * (NULL = the legacy default stream, i.e. ordered after the caller's earlier
  * default-stream work) and synchronised before returning (status needs the result). */
@@ -211,25 +250,18 @@ isl_status isl_search_batch_device_async(const isl_index* idx, const float* d_qu
                                          uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_out_ids,
                                          float* d_out_dist, uint32_t* d_out_count, void* stream,
                                          uint64_t* token);
+/* Completes the call `token` names: waits for its stream, copies host-pointer results out, turns
+ * per-query failures into the CoreError of the first failing query.  `stats` (may be NULL)
+ * receives the counters of exactly that call. */
+isl_status isl_search_wait_stats(const isl_index* idx, uint64_t token, isl_search_stats* stats);
 isl_status isl_search_wait(const isl_index* idx, uint64_t token);
 /* LeannIndex::search, leann.rs:858-865: one query, ef = config.ef_search. */
 isl_status isl_search(const isl_index* idx, const float* query, uint64_t d, uint64_t k,
                       uint64_t* out_ids, float* out_dist, uint32_t* out_count);
 
-/* Work counters of the most recent search call on this index (summed over the
- * batch): the inputs of the roofline formula. */
-typedef struct isl_search_stats {
-  uint64_t queries;
-  uint64_t expansions;     /* H: candidates expanded */
-  uint64_t edges;          /* E: neighbour ids read */
-  uint64_t evals;          /* V: embeddings fetched / distances evaluated */
-  uint64_t pushes;         /* heap insertions */
-  uint64_t exact_path;     /* queries answered by the heap-exact kernel */
-  uint64_t replayed;       /* queries whose tied prefix was re-ordered by the replay kernel */
-  double kernel_ms;        /* HIP-event time of the search kernels of that call */
-  uint64_t encoded_nodes;    /* recompute provider: embeddings computed by the encoder */
-  uint64_t recompute_rounds; /* recompute provider: search rounds of that call (0 otherwise) */
-} isl_search_stats;
+/* Counters of the most recent search call THIS THREAD completed on this index (synchronous entry
+ * points and isl_search_wait alike); zeros when there is none.  Calls made by other threads never
+ * show up here -- use isl_search_wait_stats for a per-call record. */
 isl_status isl_search_last_stats(const isl_index* idx, isl_search_stats* out);
 
 /* ---- distance.rs ---- */

@@ -172,6 +172,10 @@ class LeannIndex {
     check(isl_set_recompute_provider(h_, enc, tokens.data(), nullptr, n, L, normalize ? 1 : 0,
                                      keep_rows ? 1 : 0, ISL_MEM_HOST));
   }
+  // no reference counterpart: sets up every search lane ahead of time (isl_index_prepare)
+  void prepare(uint64_t max_nq, uint64_t max_ef, uint64_t max_k = 10, int32_t lanes = 8) {
+    check(isl_index_prepare(h_, max_nq, max_ef, max_k, lanes));
+  }
   // search / search_with_params, leann.rs:858-896
   std::vector<std::pair<uint64_t, float>> search(const std::vector<float>& query, uint64_t k) const {
     return search_with_params(query, k, config().ef_search);

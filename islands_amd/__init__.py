@@ -273,6 +273,7 @@ class LeannIndex:
     def __init__(self, config: LeannConfig | None = None, _handle=None):
         self._h = C.c_void_p()
         self._provider_key = None
+        self._pending = {}  # token -> output arrays of a host-buffer search in flight
         if _handle is not None:
             self._h = _handle
             return
@@ -536,15 +537,55 @@ class LeannIndex:
     def search_batch_device_async(self, d_queries_ptr: int, nq: int, d: int, k: int, ef: int,
                                   d_ids_ptr: int, d_dist_ptr: int, d_count_ptr: int,
                                   stream: int = 0) -> int:
-        """Enqueue a search; returns a token for wait().  Up to 4 may be in flight."""
+        """Enqueue a search; returns a token for wait().  Up to 16 may be in flight."""
         tok = C.c_uint64()
         _check(_ffi.lib().isl_search_batch_device_async(
             self._h, C.c_void_p(d_queries_ptr), nq, d, k, ef, C.c_void_p(d_ids_ptr),
             C.c_void_p(d_dist_ptr), C.c_void_p(d_count_ptr), C.c_void_p(stream), C.byref(tok)))
         return int(tok.value)
 
-    def wait(self, token: int) -> None:
-        _check(_ffi.lib().isl_search_wait(self._h, token))
+    def wait(self, token: int):
+        """Completes the call; for a host-buffer call returns its (ids, dist, count) arrays."""
+        try:  # the library writes the answers during the wait: the arrays must outlive it
+            _check(_ffi.lib().isl_search_wait(self._h, token))
+        finally:
+            out = self._pending.pop(token, None)
+        return out
+
+    def wait_stats(self, token: int) -> dict:
+        """wait() that returns the counters of exactly that call (isl_search_wait_stats)."""
+        s = SearchStatsC()
+        try:
+            _check(_ffi.lib().isl_search_wait_stats(self._h, token, C.byref(s)))
+        finally:
+            self._pending.pop(token, None)
+        return {f: getattr(s, f) for f, _ in SearchStatsC._fields_}
+
+    def prepare(self, max_nq: int, max_ef: int, max_k: int = 10, lanes: int = 8) -> "LeannIndex":
+        """isl_index_prepare: every lane's buffers, the padded adjacency and the exact-kernel pool
+        up front, so that no later search allocates (stats["allocations"] == 0)."""
+        _check(_ffi.lib().isl_index_prepare(self._h, max_nq, max_ef, max_k, lanes))
+        return self
+
+    def search_batch_async(self, queries, k: int, ef: int, out=None) -> int:
+        """Pipelined host-buffer search (isl_search_batch_async): returns a token; the arrays of
+        `out` = (ids [nq,k] u64, dist [nq,k] f32, count [nq] u32) -- allocated here when None and
+        available through result(token) -- are filled once wait(token) has returned."""
+        q = _f32(queries)
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        nq, d = q.shape
+        if out is None:
+            out = (np.zeros((nq, max(k, 1)), dtype=np.uint64), np.zeros((nq, max(k, 1)), dtype=np.float32),
+                   np.zeros(nq, dtype=np.uint32))
+        ids, dist, cnt = out
+        tok = C.c_uint64()
+        _check(_ffi.lib().isl_search_batch_async(self._h, _ptr(q), nq, d, k, ef, _ptr(ids), _ptr(dist),
+                                                 _ptr(cnt), C.byref(tok)))
+        t = int(tok.value)
+        if t:
+            self._pending[t] = out  # the library writes into them at wait(): keep them alive
+        return t
 
     def last_stats(self) -> dict:
         s = SearchStatsC()

@@ -47,7 +47,7 @@ class IndexMetadataC(C.Structure):
 class SearchStatsC(C.Structure):
     _fields_ = [("queries", u64), ("expansions", u64), ("edges", u64), ("evals", u64),
                 ("pushes", u64), ("exact_path", u64), ("replayed", u64), ("kernel_ms", C.c_double),
-                ("encoded_nodes", u64), ("recompute_rounds", u64)]
+                ("encoded_nodes", u64), ("recompute_rounds", u64), ("allocations", u64)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/islands_amd.h
@@ -100,6 +100,10 @@ SIGNATURES = {
     "isl_search_batch_device_async": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, P(u64)]),
     "isl_search_wait": (i32, [C.c_void_p, u64]),
+    "isl_search_wait_stats": (i32, [C.c_void_p, u64, P(SearchStatsC)]),
+    "isl_search_batch_async": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, P(u64)]),
+    "isl_index_prepare": (i32, [C.c_void_p, u64, u64, u64, i32]),
     "isl_search": (i32, [C.c_void_p, C.c_void_p, u64, u64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "isl_search_last_stats": (i32, [C.c_void_p, P(SearchStatsC)]),
     "isl_distance": (i32, [i32, C.c_void_p, u64, C.c_void_p, u64, P(f32)]),

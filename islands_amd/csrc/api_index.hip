@@ -81,19 +81,13 @@ int device_cu_count(int32_t device) {
 
 void free_workspace(SearchWorkspace& ws) {
   void* ptrs[] = {ws.ovf_tab, ws.status,  ws.payload,   ws.ctr,        ws.ticket,     ws.redo, ws.replay, ws.plog,
-                  ws.cand_d,  ws.cand_id, ws.vis_bits,  ws.ulist,      ws.q_stage,    ws.ids_stage,
-                  ws.dist_stage, ws.count_stage};
+                  ws.q_stage, ws.ids_stage, ws.dist_stage, ws.count_stage, ws.d_prof, ws.q_entry, ws.miss, ws.uniq,
+                  ws.uniq_count, ws.tl_tables};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  if (ws.h_status) (void)hipHostFree(ws.h_status);
-  if (ws.h_ctr) (void)hipHostFree(ws.h_ctr);
-  if (ws.h_head) (void)hipHostFree(ws.h_head);
-  if (ws.d_prof) (void)hipFree(ws.d_prof);
-  if (ws.q_entry) (void)hipFree(ws.q_entry);
-  if (ws.miss) (void)hipFree(ws.miss);
-  if (ws.uniq) (void)hipFree(ws.uniq);
-  if (ws.uniq_count) (void)hipFree(ws.uniq_count);
-  if (ws.tl_tables) (void)hipFree(ws.tl_tables);
+  void* pinned[] = {ws.h_status, ws.h_ctr, ws.h_head, ws.h_q, ws.h_ids, ws.h_dist, ws.h_count};
+  for (void* p : pinned)
+    if (p) (void)hipHostFree(p);
   if (ws.ev0) (void)hipEventDestroy(ws.ev0);
   if (ws.ev1) (void)hipEventDestroy(ws.ev1);
   if (ws.ev_in) (void)hipEventDestroy(ws.ev_in);
@@ -274,6 +268,8 @@ void isl_index_free(isl_index* idx) {
   if (!idx) return;
   if (idx->device >= 0) {
     (void)hipSetDevice(idx->device);
+    for (auto& w : idx->ws)
+      if (w.busy && w.st_inflight) (void)hipStreamSynchronize(w.st_inflight);
     if (idx->ell_owned) { (void)hipFree(idx->d_ell); (void)hipFree(idx->d_ell_deg); }
     if (idx->d_emb16) (void)hipFree(idx->d_emb16);
     if (idx->d_tokens) (void)hipFree(idx->d_tokens);
@@ -288,6 +284,7 @@ void isl_index_free(isl_index* idx) {
     if (idx->d_layer_off) (void)hipFree((void*)idx->d_layer_off);
     if (idx->d_layer_adj) (void)hipFree((void*)idx->d_layer_adj);
     for (auto& w : idx->ws) free_workspace(w);
+    free_exact_pool(idx->pool);
   }
   delete idx;
 }
@@ -407,8 +404,19 @@ isl_status isl_index_to_bytes(const isl_index* idx, uint8_t** out, size_t* len) 
 
 void isl_free_bytes(uint8_t* p) { free(p); }
 
+static isl_status index_from_bytes_impl(const uint8_t* bytes, size_t len, isl_index** out);
+
 isl_status isl_index_from_bytes(const uint8_t* bytes, size_t len, isl_index** out) {  // leann.rs:1064
   if (!bytes || !out) return fail(ISL_ERR_INVALID_ARGUMENT, "NULL argument");
+  // lengths inside the buffer are untrusted: nothing may throw across the C boundary
+  try {
+    return index_from_bytes_impl(bytes, len, out);
+  } catch (const std::exception& e) {
+    return fail(ISL_ERR_DESERIALIZATION, "Deserialization error: %s", e.what());
+  }
+}
+
+static isl_status index_from_bytes_impl(const uint8_t* bytes, size_t len, isl_index** out) {
   Reader r{bytes, len};
   isl_index* idx = new (std::nothrow) isl_index();
   if (!idx) return fail(ISL_ERR_IO, "out of memory");
@@ -438,7 +446,8 @@ isl_status isl_index_from_bytes(const uint8_t* bytes, size_t len, isl_index** ou
   }
   // bincode itself accepts trailing bytes with deserialize(); structural sanity below is
   // ours: get_neighbors (leann.rs:230-232) would index out of bounds otherwise.
-  if (idx->node_offsets.size() != idx->num_nodes + 1 ||
+  // (num_nodes is untrusted: num_nodes + 1 must not wrap before it is compared)
+  if (idx->num_nodes >= (1ull << 61) || idx->node_offsets.size() != idx->num_nodes + 1 ||
       (idx->num_nodes && idx->node_offsets[idx->num_nodes] > idx->neighbors.size())) {
     delete idx;
     return fail(ISL_ERR_DESERIALIZATION,
@@ -641,7 +650,7 @@ isl_status isl_index_upload(isl_index* idx, int32_t device) {
     nb_src = dedup.data();
   }
   (void)hipFree(d_flags);
-  return ISL_OK;
+  return ensure_padded_adjacency(idx);
 }
 
 isl_status isl_index_from_device_csr(const isl_leann_config* cfg, int32_t device,
@@ -685,6 +694,7 @@ isl_status isl_index_from_device_csr(const isl_leann_config* cfg, int32_t device
   if (flags & 6u)
     return bail(fail(ISL_ERR_UNSUPPORTED,
                      "device-born CSR rows must not repeat a neighbour id (or exceed 4096 ids)"));
+  if ((st = ensure_padded_adjacency(idx)) != ISL_OK) return bail(st);
   *out = idx;
   return ISL_OK;
 }
@@ -701,8 +711,11 @@ isl_status isl_set_embeddings(isl_index* idx, const void* rows, uint64_t n, uint
     return fail(ISL_ERR_DEVICE, "call isl_index_upload before attaching embeddings");
   ISL_TRY(use_device(idx->device));
   std::lock_guard<std::mutex> lock(idx->mu);
+  if (any_lane_busy(idx))  // their kernels read the tables freed below
+    return fail(ISL_ERR_SEARCH, "Search error: the embedding provider cannot be swapped while searches are in flight");
   if (idx->d_emb) { (void)hipFree(idx->d_emb); idx->d_emb = nullptr; }
   if (idx->d_emb16) { (void)hipFree(idx->d_emb16); idx->d_emb16 = nullptr; }
+  free_exact_pool(idx->pool);  // sized by the row count: rebuilt by the next prepare / search
   idx->recompute = false;  // back to the in-memory provider
   if (dtype == ISL_DTYPE_BF16) {
     // rows are bf16 bit patterns; the provider's vectors are their exact f32 images.  Rows start
@@ -782,12 +795,17 @@ isl_status isl_set_recompute_provider(isl_index* idx, isl_encoder* enc, const ui
   if (n > 0x7FFFFFF0ull) return fail(ISL_ERR_UNSUPPORTED, "node ids above the device id range");
   ISL_TRY(use_device(idx->device));
   std::lock_guard<std::mutex> lock(idx->mu);
+  if (any_lane_busy(idx))
+    return fail(ISL_ERR_SEARCH, "Search error: the embedding provider cannot be swapped while searches are in flight");
   const uint64_t d = enc->cfg.hidden, stride = (d + 3) / 4 * 4;
-  void* olds[] = {idx->d_emb, idx->d_norm2, idx->d_tokens, idx->d_lens, idx->d_present};
+  // (d_emb16 too: bf16 rows of an earlier in-memory provider would otherwise stay the table the
+  // searches read)
+  void* olds[] = {idx->d_emb, idx->d_emb16, idx->d_norm2, idx->d_tokens, idx->d_lens, idx->d_present};
   for (void* p : olds)
     if (p) (void)hipFree(p);
-  idx->d_emb = nullptr; idx->d_norm2 = nullptr; idx->d_tokens = nullptr; idx->d_lens = nullptr;
-  idx->d_present = nullptr;
+  idx->d_emb = nullptr; idx->d_emb16 = nullptr; idx->d_norm2 = nullptr; idx->d_tokens = nullptr;
+  idx->d_lens = nullptr; idx->d_present = nullptr;
+  free_exact_pool(idx->pool);
   idx->recompute = false;
   // the row table is addressed by node id like the in-memory provider's; rows are valid only
   // where d_present says so (288 GB of HBM make a dense table the simplest cache)

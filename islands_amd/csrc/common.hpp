@@ -46,6 +46,10 @@ isl_status use_device(int32_t device);
 int device_cu_count(int32_t device);
 
 // ---- per-index device workspace for the search kernels ----
+// One lane = everything one search in flight needs: a stream, events, per-query device arrays,
+// pinned host mirrors and (host-pointer entry points) staging buffers.  A lane is claimed under
+// isl_index::mu and then touched by its owner alone until it is released, so the entry points do
+// not hold the index mutex while they enqueue, wait or copy.
 struct SearchWorkspace {
   uint32_t slots = 0;          // resident waves the scratch is sized for
   uint32_t ovf_bits = 0;       // log2 entries of the per-slot overflow visited table
@@ -59,30 +63,34 @@ struct SearchWorkspace {
   uint32_t* replay = nullptr;  // [cap_q] query ids routed to the replay kernel
   uint64_t* plog = nullptr;    // [cap_q][plog_cap] push log (distance bits, id)
   uint64_t plog_entries = 0;
-  // exact-kernel scratch
-  uint32_t exact_slots = 0;
-  uint64_t cand_cap = 0;       // entries per slot in the candidate heap
-  float* cand_d = nullptr;     // [exact_slots][cand_cap]
-  uint32_t* cand_id = nullptr;
-  uint32_t* vis_bits = nullptr; // [exact_slots][ceil(max_id/32)] visited bitmap
-  uint64_t vis_words = 0;
-  uint32_t* ulist = nullptr;   // [exact_slots][max_degree] unvisited ids of one hop
-  uint32_t ulist_cap = 0;
-  // staging for the host-pointer entry point
+  // staging for the host-pointer entry points: device side ...
   float* q_stage = nullptr;
   uint64_t q_stage_bytes = 0;
   uint64_t* ids_stage = nullptr;
   float* dist_stage = nullptr;
   uint32_t* count_stage = nullptr;
   uint64_t out_stage_slots = 0;
+  // ... and pinned host side (the caller's buffers are pageable: copied through these)
+  float* h_q = nullptr;
+  uint64_t h_q_bytes = 0;
+  uint64_t* h_ids = nullptr;
+  float* h_dist = nullptr;
+  uint32_t* h_count = nullptr;
+  uint64_t h_out_slots = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_in = nullptr;
-  // call in flight on this lane (isl_search_batch_device_async .. isl_search_wait)
-  bool busy = false;
+  // call in flight on this lane (claim .. release)
+  bool busy = false;           // under isl_index::mu
+  bool waiting = false;        // a thread is inside isl_search_wait for this lane (under mu)
+  bool enqueued = false;       // kernels of a call are on the stream (owner only)
   uint64_t token = 0;
-  uint64_t nq_inflight = 0;
+  uint64_t nq_inflight = 0, k_inflight = 0;
   bool fast_inflight = false;
   hipStream_t st_inflight = nullptr;
+  // host-pointer call in flight: where the answers go at wait time
+  uint64_t* u_ids = nullptr;
+  float* u_dist = nullptr;
+  uint32_t* u_count = nullptr;
   uint32_t* h_status = nullptr;  // pinned host mirrors of status / ctr / ticket
   uint32_t* h_ctr = nullptr;
   uint32_t* h_head = nullptr;
@@ -98,9 +106,29 @@ struct SearchWorkspace {
   // two-level search: per-query PQ distance tables [nq][m * K]
   float* tl_tables = nullptr;
   uint64_t tl_tables_cap = 0;
+  // device / pinned-host allocations, stream and event creations made for this lane so far: a
+  // call's share of it is reported in isl_search_stats::allocations (0 after isl_index_prepare)
+  uint64_t alloc_events = 0;
+  uint64_t alloc_mark = 0;       // alloc_events when the call in flight was claimed
+  isl_search_stats stats{};      // statistics of the call that finished last on this lane
 };
 
 constexpr int kSearchLanes = 16;  // independent workspaces = searches that may be in flight
+
+// Scratch of the heap-exact kernel, ONE pool per index shared by every lane: a workgroup that
+// finds work in its redo queue claims a free slot (lock word per slot), so concurrent searches
+// do not need a private copy each.
+struct ExactPool {
+  uint32_t slots = 0;
+  uint64_t cand_cap = 0;        // entries per slot in the candidate heap
+  float* cand_d = nullptr;      // [slots][cand_cap]
+  uint32_t* cand_id = nullptr;
+  uint32_t* vis_bits = nullptr; // [slots][vis_words] visited bitmap
+  uint64_t vis_words = 0;
+  uint32_t* ulist = nullptr;    // [slots][ulist_cap] unvisited ids of one hop
+  uint32_t ulist_cap = 0;
+  uint32_t* locks = nullptr;    // [slots] 0 = free, 1 = held by a workgroup
+};
 
 }  // namespace isl
 
@@ -171,10 +199,11 @@ struct isl_index {
   uint16_t* d_codes = nullptr;
   uint64_t ncodes = 0;
 
-  mutable std::mutex mu;  // serialises searches that share the workspace
+  mutable std::mutex mu;  // lane claims, the exact pool, index mutation -- never held across a search
+  mutable std::mutex recompute_mu;  // searches over the recompute provider share its row table
   mutable isl::SearchWorkspace ws[isl::kSearchLanes];
+  mutable isl::ExactPool pool;
   mutable uint64_t next_token = 1;
-  mutable isl_search_stats stats{};
 };
 
 namespace isl {
@@ -188,4 +217,10 @@ isl_status materialise_host_csr(const isl_index* idx);
 isl_status pq_launch_tables(const isl_pq* pq, const float* d_queries, uint64_t nq, float* d_tables,
                             hipStream_t st);
 void free_workspace(SearchWorkspace& ws);
+void free_exact_pool(ExactPool& pool);
+// true while a search is in flight on any lane (call under idx->mu): provider / PQ setters and
+// isl_index_free must not free tables such a search reads
+bool any_lane_busy(const isl_index* idx);
+// Builds the padded adjacency (64 ids per node + degrees) the traversal reads; under idx->mu.
+isl_status ensure_padded_adjacency(isl_index* idx);
 }  // namespace isl

@@ -130,8 +130,19 @@ isl_status isl_hnsw_from_layers(uint64_t m, uint64_t m0, uint64_t ef_constructio
 // The byte layout is unpinned by the reference (tests round-trip only, hnsw.rs:689-709) and the
 // pinned bincode is 3.0.0 (Cargo.lock:838-841); this is the documented 1.x-compatible intent.
 // Node ids must be 0..n-1 (insert assigns them from next_id, hnsw.rs:218-219), in any order.
+static isl_status hnsw_from_bytes_impl(const uint8_t* bytes, size_t len, int32_t device, isl_hnsw** out);
+
 isl_status isl_hnsw_from_bytes(const uint8_t* bytes, size_t len, int32_t device, isl_hnsw** out) {
   if (!out || (!bytes && len)) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL argument");
+  // every length in the buffer is untrusted: nothing may throw across the C boundary
+  try {
+    return hnsw_from_bytes_impl(bytes, len, device, out);
+  } catch (const std::exception& e) {
+    return isl::fail(ISL_ERR_DESERIALIZATION, "Deserialization error: %s", e.what());
+  }
+}
+
+static isl_status hnsw_from_bytes_impl(const uint8_t* bytes, size_t len, int32_t device, isl_hnsw** out) {
   size_t pos = 0;
   bool ok = true;
   auto need = [&](size_t n) { if (ok && len - pos < n) ok = false; return ok; };
@@ -162,7 +173,13 @@ isl_status isl_hnsw_from_bytes(const uint8_t* bytes, size_t len, int32_t device,
     if (id >= n || seen[id]) return isl::fail(ISL_ERR_UNSUPPORTED, "HnswGraph node ids must be 0..n-1 (id %llu of %llu nodes)",
                                               (unsigned long long)id, (unsigned long long)n);
     seen[id] = 1;
-    if (e == 0) { d = vlen; vectors.assign((size_t)n * d, 0.0f); }
+    // vlen * 4 and n * d must not wrap: every node carries its vector inside the buffer
+    if (vlen > (len - pos) / 4) return bad("vector length exceeds the buffer");
+    if (e == 0) {
+      d = vlen;
+      if (d && n > (len / 4) / d) return bad("node count times vector length exceeds the buffer");
+      vectors.assign((size_t)n * d, 0.0f);
+    }
     if (vlen != d) return bad("nodes with different vector lengths");
     if (!need(vlen * 4)) break;
     memcpy(vectors.data() + (size_t)id * d, bytes + pos, vlen * 4);

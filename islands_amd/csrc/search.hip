@@ -86,6 +86,8 @@ struct SearchParams {
   uint64_t vis_words;
   uint32_t* ulist;
   uint32_t ulist_cap;
+  uint32_t* pool_locks;  // [pool_slots] lock word per slot of the shared exact-kernel scratch pool
+  uint32_t pool_slots;
   // graph under construction (build.hip): row i = adj[i * ell_w .. + ell_deg[i]), `off` unused
   uint32_t ell_w;
   const uint32_t* ell_deg;
@@ -847,10 +849,14 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
   float* qs = reinterpret_cast<float*>(res_i + (ef + 1));
   qs = reinterpret_cast<float*>(((uintptr_t)qs + 15) & ~(uintptr_t)15);
 
-  float* cand_d = p.cand_d + (size_t)blockIdx.x * p.cand_cap;
-  uint32_t* cand_i = p.cand_id + (size_t)blockIdx.x * p.cand_cap;
-  uint32_t* vis = p.vis_bits + (size_t)blockIdx.x * p.vis_words;
-  uint32_t* ulist = p.ulist + (size_t)blockIdx.x * p.ulist_cap;
+  // The scratch (candidate heap, visited bitmap, hop list) comes from the pool every lane of the
+  // index shares: a workgroup that finds work claims a free slot and keeps it until its queue is
+  // empty.  Holders never wait for anything, so a spinning claimant always gets one.
+  uint32_t slot = 0xFFFFFFFFu;
+  float* cand_d = nullptr;
+  uint32_t* cand_i = nullptr;
+  uint32_t* vis = nullptr;
+  uint32_t* ulist = nullptr;
 
   for (;;) {
     uint32_t t = 0;
@@ -859,6 +865,25 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
     uint32_t nredo = *((volatile uint32_t*)&p.ticket[1]);
     if (t >= nredo) break;
     const uint32_t qi = p.redo[t];
+    if (slot == 0xFFFFFFFFu) {
+      uint32_t sl = 0;
+      if (lane == 0) {
+        sl = blockIdx.x % p.pool_slots;
+        while (atomicCAS(&p.pool_locks[sl], 0u, 1u) != 0u) {
+          sl = sl + 1 == p.pool_slots ? 0u : sl + 1;
+          __builtin_amdgcn_s_sleep(16);
+        }
+      }
+      slot = uni(sl);
+      // the previous holder may have run on another CU: nothing of its bytes is read here (the
+      // bitmap is cleared, heap and list entries are written before they are read), the acquire
+      // only keeps this CU's L1 from serving lines it cached during an earlier tenure
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      cand_d = p.cand_d + (size_t)slot * p.cand_cap;
+      cand_i = p.cand_id + (size_t)slot * p.cand_cap;
+      vis = p.vis_bits + (size_t)slot * p.vis_words;
+      ulist = p.ulist + (size_t)slot * p.ulist_cap;
+    }
 
     for (uint64_t i = lane; i < p.vis_words; i += 64) vis[i] = 0u;
     const float q_norm = load_query<METRIC>(p.queries + (uint64_t)qi * p.d, p.d, qs);
@@ -1074,6 +1099,11 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
       p.ctr[qi * 4 + 3] = cP;
     }
     __syncthreads();
+  }
+  if (slot != 0xFFFFFFFFu) {
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) atomicExch(&p.pool_locks[slot], 0u);
   }
 }
 
@@ -1480,43 +1510,79 @@ constexpr uint32_t kExactSlots = 32;
 constexpr uint32_t kOvfBits = 15;
 constexpr uint32_t kMaxExactEf = 4096;
 
+// Every allocation of the search path goes through these: a lane counts what it had to set up,
+// and a call reports its share in isl_search_stats::allocations (0 once isl_index_prepare has run).
 template <typename T>
-isl_status ensure(T*& ptr, uint64_t& have, uint64_t want) {
+isl_status lane_malloc(isl::SearchWorkspace& ws, T*& ptr, size_t bytes) {
+  ptr = nullptr;
+  ISL_HIP(hipMalloc(&ptr, bytes ? bytes : 4));
+  ws.alloc_events++;
+  return ISL_OK;
+}
+template <typename T>
+isl_status lane_host_malloc(isl::SearchWorkspace& ws, T*& ptr, size_t bytes) {
+  ptr = nullptr;
+  ISL_HIP(hipHostMalloc(&ptr, bytes ? bytes : 4));
+  ws.alloc_events++;
+  return ISL_OK;
+}
+template <typename T>
+isl_status ensure(isl::SearchWorkspace& ws, T*& ptr, uint64_t& have, uint64_t want) {
   if (have >= want && ptr) return ISL_OK;
   if (ptr) (void)hipFree(ptr);
   ptr = nullptr;
   have = 0;
-  ISL_HIP(hipMalloc(&ptr, want * sizeof(T)));
+  ISL_TRY(lane_malloc(ws, ptr, want * sizeof(T)));
   have = want;
+  return ISL_OK;
+}
+
+// resident waves per CU the launch geometry may count on (ISL_WAVES_PER_CU: experiments only)
+size_t waves_per_cu_cap() {
+  static const size_t cap = [] {
+    const char* wc = getenv("ISL_WAVES_PER_CU");
+    return wc ? (size_t)std::max(1, atoi(wc)) : (size_t)16;
+  }();
+  return cap;
+}
+uint32_t push_log_cap(uint32_t ef) { return std::max<uint32_t>(1024, 12 * ef); }  // pushes per query ~ 3-6 x ef
+
+// Streams, events, per-query arrays, overflow table, push log of one lane, sized for nq queries
+// on `slots` resident waves.
+isl_status ensure_lane_stream(isl::SearchWorkspace& ws) {
+  if (ws.stream) return ISL_OK;
+  hipStream_t st = nullptr;
+  ISL_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  ws.alloc_events++;
+  if (!ws.ev0) { ISL_HIP(hipEventCreate(&ws.ev0)); ws.alloc_events++; }
+  if (!ws.ev1) { ISL_HIP(hipEventCreate(&ws.ev1)); ws.alloc_events++; }
+  if (!ws.ev_in) { ISL_HIP(hipEventCreateWithFlags(&ws.ev_in, hipEventDisableTiming)); ws.alloc_events++; }
+  if (!ws.ticket) ISL_TRY(lane_malloc(ws, ws.ticket, 64));
+  if (!ws.h_head) ISL_TRY(lane_host_malloc(ws, ws.h_head, 64));
+  ws.stream = st;
   return ISL_OK;
 }
 
 isl_status prepare_workspace(isl::SearchWorkspace& ws, uint32_t nq, uint32_t slots,
                              uint32_t plog_cap) {
-  if (!ws.stream) {
-    ISL_HIP(hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking));
-    ISL_HIP(hipEventCreate(&ws.ev0));
-    ISL_HIP(hipEventCreate(&ws.ev1));
-    ISL_HIP(hipEventCreateWithFlags(&ws.ev_in, hipEventDisableTiming));
-    ISL_HIP(hipMalloc(&ws.ticket, 64));
-    ISL_HIP(hipHostMalloc(&ws.h_head, 64));
-  }
+  ISL_TRY(ensure_lane_stream(ws));
   if (ws.h_cap < nq) {
     if (ws.h_status) (void)hipHostFree(ws.h_status);
     if (ws.h_ctr) (void)hipHostFree(ws.h_ctr);
     ws.h_status = ws.h_ctr = nullptr;
     ws.h_cap = 0;
     uint64_t cap = nq < 1024 ? 1024 : nq;
-    ISL_HIP(hipHostMalloc(&ws.h_status, cap * 4));
-    ISL_HIP(hipHostMalloc(&ws.h_ctr, cap * 16));
+    ISL_TRY(lane_host_malloc(ws, ws.h_status, cap * 4));
+    ISL_TRY(lane_host_malloc(ws, ws.h_ctr, cap * 16));
     ws.h_cap = cap;
   }
   if (ws.slots < slots || !ws.ovf_tab) {
     if (ws.ovf_tab) (void)hipFree(ws.ovf_tab);
     ws.ovf_tab = nullptr;
+    ws.slots = 0;
     ws.ovf_bits = kOvfBits;
     uint64_t n = (uint64_t)slots << kOvfBits;
-    ISL_HIP(hipMalloc(&ws.ovf_tab, n * 4));
+    ISL_TRY(lane_malloc(ws, ws.ovf_tab, n * 4));
     hipLaunchKernelGGL(fill_u32_kernel, dim3(2048), dim3(256), 0, ws.stream, ws.ovf_tab, n, EMPTY);
     ISL_HIP(hipGetLastError());
     ISL_HIP(hipStreamSynchronize(ws.stream));
@@ -1530,11 +1596,11 @@ isl_status prepare_workspace(isl::SearchWorkspace& ws, uint32_t nq, uint32_t slo
     ws.replay = nullptr;
     ws.cap_q = 0;
     uint32_t cap = nq < 1024 ? 1024 : nq;
-    ISL_HIP(hipMalloc(&ws.status, (size_t)cap * 4));
-    ISL_HIP(hipMalloc(&ws.payload, (size_t)cap * 8));
-    ISL_HIP(hipMalloc(&ws.ctr, (size_t)cap * 16));
-    ISL_HIP(hipMalloc(&ws.redo, (size_t)cap * 4));
-    ISL_HIP(hipMalloc(&ws.replay, (size_t)cap * 4));
+    ISL_TRY(lane_malloc(ws, ws.status, (size_t)cap * 4));
+    ISL_TRY(lane_malloc(ws, ws.payload, (size_t)cap * 8));
+    ISL_TRY(lane_malloc(ws, ws.ctr, (size_t)cap * 16));
+    ISL_TRY(lane_malloc(ws, ws.redo, (size_t)cap * 4));
+    ISL_TRY(lane_malloc(ws, ws.replay, (size_t)cap * 4));
     ws.cap_q = cap;
   }
   uint64_t want_log = (uint64_t)ws.cap_q * plog_cap;
@@ -1542,34 +1608,78 @@ isl_status prepare_workspace(isl::SearchWorkspace& ws, uint32_t nq, uint32_t slo
     if (ws.plog) (void)hipFree(ws.plog);
     ws.plog = nullptr;
     ws.plog_entries = 0;
-    ISL_HIP(hipMalloc(&ws.plog, want_log * 8));
+    ISL_TRY(lane_malloc(ws, ws.plog, want_log * 8));
     ws.plog_entries = want_log;
   }
   return ISL_OK;
 }
 
-isl_status prepare_exact(const isl_index* idx, isl::SearchWorkspace& ws) {
-  uint64_t max_id = std::max(idx->num_nodes, idx->nvec);
-  uint64_t words = (max_id + 31) / 32 + 1;
-  uint64_t cand_cap = std::min<uint64_t>(max_id + 1, 1ull << 21);
-  uint32_t ucap = std::max<uint32_t>(idx->max_degree, 64);
-  if (ws.exact_slots == kExactSlots && ws.vis_words >= words && ws.cand_cap >= cand_cap &&
-      ws.ulist_cap >= ucap)
-    return ISL_OK;
-  void* ptrs[] = {ws.cand_d, ws.cand_id, ws.vis_bits, ws.ulist};
-  for (void* q : ptrs)
-    if (q) (void)hipFree(q);
-  ws.cand_d = nullptr; ws.cand_id = nullptr; ws.vis_bits = nullptr; ws.ulist = nullptr;
-  ws.exact_slots = 0;
-  ISL_HIP(hipMalloc(&ws.cand_d, (size_t)kExactSlots * cand_cap * 4));
-  ISL_HIP(hipMalloc(&ws.cand_id, (size_t)kExactSlots * cand_cap * 4));
-  ISL_HIP(hipMalloc(&ws.vis_bits, (size_t)kExactSlots * words * 4));
-  ISL_HIP(hipMalloc(&ws.ulist, (size_t)kExactSlots * ucap * 4));
-  ws.exact_slots = kExactSlots;
-  ws.cand_cap = cand_cap;
-  ws.vis_words = words;
-  ws.ulist_cap = ucap;
+// Staging of the host-pointer entry points: device buffers + pinned host mirrors.
+isl_status prepare_host_staging(isl::SearchWorkspace& ws, uint64_t nq, uint64_t d, uint64_t k) {
+  const uint64_t qbytes = nq * d * 4;
+  if (ws.q_stage_bytes < qbytes) {
+    if (ws.q_stage) (void)hipFree(ws.q_stage);
+    ws.q_stage = nullptr;
+    ws.q_stage_bytes = 0;
+    ISL_TRY(lane_malloc(ws, ws.q_stage, qbytes));
+    ws.q_stage_bytes = qbytes;
+  }
+  if (ws.h_q_bytes < qbytes) {
+    if (ws.h_q) (void)hipHostFree(ws.h_q);
+    ws.h_q = nullptr;
+    ws.h_q_bytes = 0;
+    ISL_TRY(lane_host_malloc(ws, ws.h_q, qbytes));
+    ws.h_q_bytes = qbytes;
+  }
+  const uint64_t slots = nq * std::max<uint64_t>(k, 1);
+  if (ws.out_stage_slots < slots) {
+    void* ptrs[] = {ws.ids_stage, ws.dist_stage, ws.count_stage};
+    for (void* q : ptrs)
+      if (q) (void)hipFree(q);
+    ws.ids_stage = nullptr; ws.dist_stage = nullptr; ws.count_stage = nullptr;
+    ws.out_stage_slots = 0;
+    ISL_TRY(lane_malloc(ws, ws.ids_stage, slots * 8));
+    ISL_TRY(lane_malloc(ws, ws.dist_stage, slots * 4));
+    ISL_TRY(lane_malloc(ws, ws.count_stage, slots * 4));
+    ws.out_stage_slots = slots;
+  }
+  if (ws.h_out_slots < slots) {
+    void* ptrs[] = {ws.h_ids, ws.h_dist, ws.h_count};
+    for (void* q : ptrs)
+      if (q) (void)hipHostFree(q);
+    ws.h_ids = nullptr; ws.h_dist = nullptr; ws.h_count = nullptr;
+    ws.h_out_slots = 0;
+    ISL_TRY(lane_host_malloc(ws, ws.h_ids, slots * 8));
+    ISL_TRY(lane_host_malloc(ws, ws.h_dist, slots * 4));
+    ISL_TRY(lane_host_malloc(ws, ws.h_count, slots * 4));
+    ws.h_out_slots = slots;
+  }
   return ISL_OK;
+}
+
+// The shared scratch pool of the heap-exact kernel (under idx->mu).  Its sizes follow the index
+// (node / row count, longest row); the setters that change those drop the pool.
+isl_status ensure_pool(const isl_index* idx, isl::SearchWorkspace& ws) {
+  isl::ExactPool& pl = idx->pool;
+  if (pl.slots) return ISL_OK;
+  uint64_t max_id = std::max(idx->num_nodes, idx->nvec);
+  pl.vis_words = (max_id + 31) / 32 + 1;
+  pl.cand_cap = std::min<uint64_t>(max_id + 1, 1ull << 21);
+  pl.ulist_cap = std::max<uint32_t>(idx->max_degree, 64);
+  isl_status st = ISL_OK;
+  if ((st = lane_malloc(ws, pl.cand_d, (size_t)kExactSlots * pl.cand_cap * 4)) == ISL_OK &&
+      (st = lane_malloc(ws, pl.cand_id, (size_t)kExactSlots * pl.cand_cap * 4)) == ISL_OK &&
+      (st = lane_malloc(ws, pl.vis_bits, (size_t)kExactSlots * pl.vis_words * 4)) == ISL_OK &&
+      (st = lane_malloc(ws, pl.ulist, (size_t)kExactSlots * pl.ulist_cap * 4)) == ISL_OK &&
+      (st = lane_malloc(ws, pl.locks, (size_t)kExactSlots * 4)) == ISL_OK) {
+    if (hipMemset(pl.locks, 0, (size_t)kExactSlots * 4) == hipSuccess) {
+      pl.slots = kExactSlots;
+      return ISL_OK;
+    }
+    st = isl::fail(ISL_ERR_DEVICE, "hipMemset failed for the exact-kernel pool");
+  }
+  isl::free_exact_pool(pl);
+  return st;
 }
 
 // CSR -> 64 ids per node (EMPTY-padded) + degree; one wave per row
@@ -1591,74 +1701,80 @@ __global__ void pad_rows_kernel(const uint64_t* __restrict__ off, const uint32_t
 // overlap (asynchronous entry point).
 enum class StreamMode { OWN, USER, OWN_AFTER_USER };
 
-// Enqueues the kernels of one search on a free lane; every pointer is a device pointer.
-isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const float* d_queries,
-                          uint64_t nq, uint64_t d, uint64_t k, uint64_t ef_in, uint64_t* d_ids,
-                          float* d_dist, uint32_t* d_count, hipStream_t user_stream,
-                          StreamMode mode, const TwoLevelCall* tl = nullptr) {
-  const uint32_t ef = (uint32_t)std::max(ef_in, k);  // leann.rs:890
-  if (ef > kMaxExactEf)
-    return isl::fail(ISL_ERR_UNSUPPORTED, "ef = %u exceeds the device limit %u", ef, kMaxExactEf);
-  if (nq > 0x7FFFFFFFull) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "too many queries");
-
-  const int ncu = isl::device_cu_count(idx->device);
-
-  FastGeom fg = fast_geometry(ef, (uint32_t)d);
-  bool use_fast = ef <= 512 && ef >= 1 && idx->max_degree <= 64;
-  // resident waves per CU: bounded by LDS (visited table + query) and by the kernel's VGPR
-  // budget (<= 128 -> 4 per SIMD)
-  static const size_t cu_cap = [] {
-    const char* wc = getenv("ISL_WAVES_PER_CU");
-    return wc ? (size_t)std::max(1, atoi(wc)) : (size_t)16;
-  }();
-  uint32_t per_cu = (uint32_t)std::min<size_t>(cu_cap, (160 * 1024) / fg.lds);
-  if (per_cu == 0) use_fast = false;
+// Launch geometry of one call: which kernel answers it and what its lane must hold.
+struct CallGeometry {
+  uint32_t ef = 0;
+  bool use_fast = false;
+  FastGeom fg{};
+  uint32_t slots = 0;      // resident waves of the launch
+  uint32_t plog_cap = 0;
   uint32_t tl_wcap = 0;
   size_t tl_lds = 0;
+};
+
+isl_status call_geometry(const isl_index* idx, uint64_t d, uint64_t k, uint64_t ef_in, const TwoLevelCall* tl,
+                         CallGeometry& g) {
+  g.ef = (uint32_t)std::min<uint64_t>(std::max(ef_in, k), 0xFFFFFFFFull);  // leann.rs:890
+  if (std::max(ef_in, k) > kMaxExactEf)
+    return isl::fail(ISL_ERR_UNSUPPORTED, "ef = %llu exceeds the device limit %u",
+                     (unsigned long long)std::max(ef_in, k), kMaxExactEf);
+  const uint32_t ef = g.ef;
+  const int ncu = isl::device_cu_count(idx->device);
+  g.fg = fast_geometry(ef, (uint32_t)d);
+  g.use_fast = ef <= 512 && ef >= 1 && idx->max_degree <= 64;
+  // resident waves per CU: bounded by LDS (visited table + query) and by the kernel's VGPR
+  // budget (<= 128 -> 4 per SIMD)
+  const size_t cu_cap = waves_per_cu_cap();
+  uint32_t per_cu = (uint32_t)std::min<size_t>(cu_cap, (160 * 1024) / g.fg.lds);
+  if (per_cu == 0) g.use_fast = false;
   if (tl) {
     // window of the approximate queue: ceil(a * |AQ|) must stay inside it; |AQ| is bounded by the
     // node count and, in practice, by a few dozen times ef
-    use_fast = false;
+    g.use_fast = false;
     const float a = tl->ratio > 0.0f ? std::min(tl->ratio, 1.0f) : 0.0f;
     const double bound = (double)std::min<uint64_t>(idx->ncodes, (uint64_t)32 * ef * tl->window_scale);
     const uint64_t want = (uint64_t)(a * bound) + 64;
-    tl_wcap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((want + 63) / 64 * 64, 256), 16384);
-    while (tl_wcap > 256 && two_level_lds(fg.hbits, tl_wcap, ef, (uint32_t)d) > 160 * 1024) tl_wcap -= 64;
-    tl_lds = two_level_lds(fg.hbits, tl_wcap, ef, (uint32_t)d);
-    if (tl_lds > 160 * 1024)
+    g.tl_wcap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((want + 63) / 64 * 64, 256), 16384);
+    while (g.tl_wcap > 256 && two_level_lds(g.fg.hbits, g.tl_wcap, ef, (uint32_t)d) > 160 * 1024) g.tl_wcap -= 64;
+    g.tl_lds = two_level_lds(g.fg.hbits, g.tl_wcap, ef, (uint32_t)d);
+    if (g.tl_lds > 160 * 1024)
       return isl::fail(ISL_ERR_UNSUPPORTED, "two-level search: ef = %u, d = %llu do not fit the LDS", ef,
                        (unsigned long long)d);
-    per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(cu_cap, (160 * 1024) / tl_lds));
+    per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(cu_cap, (160 * 1024) / g.tl_lds));
   }
-  uint32_t slots = std::max<uint32_t>(1, (uint32_t)ncu * std::max<uint32_t>(per_cu, 1));
-  const uint32_t plog_cap = std::max<uint32_t>(1024, 12 * ef);  // pushes per query ~ 3-6 x ef
+  g.slots = std::max<uint32_t>(1, (uint32_t)ncu * std::max<uint32_t>(per_cu, 1));
+  g.plog_cap = push_log_cap(ef);
+  return ISL_OK;
+}
+
+// Enqueues the kernels of one search on a claimed lane; every pointer is a device pointer.
+// warm = true: the same launches over zero queries (isl_index_prepare: loads the code objects and
+// brings the lane's stream up) -- nothing is read or written beyond the ticket words.
+isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const float* d_queries,
+                          uint64_t nq, uint64_t d, uint64_t k, uint64_t ef_in, uint64_t* d_ids,
+                          float* d_dist, uint32_t* d_count, hipStream_t user_stream,
+                          StreamMode mode, const TwoLevelCall* tl = nullptr, bool warm = false) {
+  if (nq > 0x7FFFFFFFull) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "too many queries");
+  CallGeometry cg;
+  ISL_TRY(call_geometry(idx, d, k, ef_in, tl, cg));
+  const uint32_t ef = cg.ef;
+  const bool use_fast = cg.use_fast;
+  const FastGeom& fg = cg.fg;
+  const uint32_t slots = cg.slots, plog_cap = cg.plog_cap;
   // per-slot state is indexed by blockIdx.x < min(nq, slots)
-  ISL_TRY(prepare_workspace(ws, (uint32_t)nq, (uint32_t)std::min<uint64_t>(nq, slots), plog_cap));
-  ISL_TRY(prepare_exact(idx, ws));
+  if (!warm) ISL_TRY(prepare_workspace(ws, (uint32_t)nq, (uint32_t)std::min<uint64_t>(nq, slots), plog_cap));
+  if (!idx->pool.slots || ((use_fast || (tl && idx->max_degree <= 64)) && !idx->d_ell && idx->d_off && idx->num_nodes)) {
+    // not prepared (isl_index_prepare / isl_index_upload do this ahead of time)
+    std::lock_guard<std::mutex> lock(idx->mu);
+    ISL_TRY(ensure_pool(idx, ws));
+    const uint32_t* before = idx->d_ell;
+    ISL_TRY(isl::ensure_padded_adjacency(const_cast<isl_index*>(idx)));
+    if (idx->d_ell != before) ws.alloc_events += 2;
+  }
   hipStream_t st = mode == StreamMode::USER ? user_stream : ws.stream;
   if (mode == StreamMode::OWN_AFTER_USER) {
     ISL_HIP(hipEventRecord(ws.ev_in, user_stream));
     ISL_HIP(hipStreamWaitEvent(ws.stream, ws.ev_in, 0));
-  }
-
-  if ((use_fast || (tl && idx->max_degree <= 64)) && !idx->d_ell && idx->d_off && idx->num_nodes) {
-    // padded copy of the adjacency (64 ids per node + a degree array): 260 bytes per node buy the
-    // traversal one dependent memory round trip per hop
-    isl_index* mi = const_cast<isl_index*>(idx);
-    const uint64_t n = idx->num_nodes;
-    if (hipMalloc(&mi->d_ell, n * 64 * 4) == hipSuccess && hipMalloc(&mi->d_ell_deg, n * 4) == hipSuccess) {
-      hipLaunchKernelGGL(pad_rows_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, idx->d_off, idx->d_adj, n,
-                         mi->d_ell, mi->d_ell_deg);
-      ISL_HIP(hipGetLastError());
-      ISL_HIP(hipStreamSynchronize(st));  // once: searches on other lanes may start right away
-      mi->ell_w = 64;
-      mi->ell_owned = true;
-    } else {  // not enough memory: stay on the CSR
-      (void)hipGetLastError();
-      if (mi->d_ell) (void)hipFree(mi->d_ell);
-      mi->d_ell = nullptr;
-      mi->d_ell_deg = nullptr;
-    }
   }
 
   SearchParams p{};
@@ -1674,7 +1790,7 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   p.stride = idx->emb_stride;
   p.d = (uint32_t)d;
   p.queries = d_queries;
-  p.nq = (uint32_t)nq;
+  p.nq = warm ? 0u : (uint32_t)nq;
   p.k = (uint32_t)k;
   p.ef = ef;
   p.prune_ratio = idx->cfg.prune_ratio;
@@ -1690,7 +1806,7 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   p.redo = ws.redo;
   if (ws.d_prof) { (void)hipFree(ws.d_prof); ws.d_prof = nullptr; }
   static const bool debug_env = getenv("ISL_DEBUG") != nullptr;
-  if (debug_env) {
+  if (debug_env && !warm) {
     ISL_HIP(hipMalloc(&ws.d_prof, nq * 64));
     ISL_HIP(hipMemset(ws.d_prof, 0, nq * 64));
   }
@@ -1701,13 +1817,15 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   p.hbits = fg.hbits;
   p.otab = ws.ovf_tab;
   p.obits = ws.ovf_bits;
-  p.cand_d = ws.cand_d;
-  p.cand_id = ws.cand_id;
-  p.cand_cap = ws.cand_cap;
-  p.vis_bits = ws.vis_bits;
-  p.vis_words = ws.vis_words;
-  p.ulist = ws.ulist;
-  p.ulist_cap = ws.ulist_cap;
+  p.cand_d = idx->pool.cand_d;
+  p.cand_id = idx->pool.cand_id;
+  p.cand_cap = idx->pool.cand_cap;
+  p.vis_bits = idx->pool.vis_bits;
+  p.vis_words = idx->pool.vis_words;
+  p.ulist = idx->pool.ulist;
+  p.ulist_cap = idx->pool.ulist_cap;
+  p.pool_locks = idx->pool.locks;
+  p.pool_slots = idx->pool.slots;
   p.present = idx->recompute ? idx->d_present : nullptr;
   p.miss = ws.miss;
   p.miss_cap = (uint32_t)std::min<uint64_t>(ws.miss_cap, 0xFFFFFFFFull);
@@ -1721,40 +1839,35 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   p.seq_max = seq_max_env;
   if (tl) {
     const isl_pq* pq = idx->pq;
-    const uint64_t want = nq * pq->m * pq->K;
-    ISL_TRY(ensure(ws.tl_tables, ws.tl_tables_cap, want));
+    const uint64_t want = std::max<uint64_t>(nq, 1) * pq->m * pq->K;
+    ISL_TRY(ensure(ws, ws.tl_tables, ws.tl_tables_cap, want));
     p.tl_tables = ws.tl_tables;
     p.tl_codes = idx->d_codes;
     p.tl_ncodes = idx->ncodes;
     p.tl_m = (uint32_t)pq->m;
     p.tl_K = (uint32_t)pq->K;
     p.tl_ratio = tl->ratio;
-    p.tl_wcap = tl_wcap;
+    p.tl_wcap = cg.tl_wcap;
   }
+  const uint64_t nq_grid = warm ? 1 : nq;  // a warm launch needs one workgroup to exist
 
   ISL_HIP(hipMemsetAsync(ws.ticket, 0, 64, st));
   ISL_HIP(hipEventRecord(ws.ev0, st));
   if (tl) {
     // build_distance_tables for the whole batch (pq.rs:307-338), then one wave per query
-    ISL_TRY(isl::pq_launch_tables(idx->pq, d_queries, nq, ws.tl_tables, st));
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, slots);
-    launch_two_level((int)idx->cfg.metric, grid, tl_lds, st, p);
+    if (!warm) ISL_TRY(isl::pq_launch_tables(idx->pq, d_queries, nq, ws.tl_tables, st));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(nq_grid, slots);
+    launch_two_level((int)idx->cfg.metric, grid, cg.tl_lds, st, p);
     ISL_HIP(hipGetLastError());
   } else
   if (use_fast && idx->is_hnsw && p.max_level > 0) {
     // HnswGraph::search: greedy descent through the upper layers first (its own kernel, so that
     // the traversal kernel keeps its register budget)
-    if (ws.q_entry_cap < nq) {
-      if (ws.q_entry) (void)hipFree(ws.q_entry);
-      ws.q_entry = nullptr;
-      ws.q_entry_cap = 0;
-      ISL_HIP(hipMalloc(&ws.q_entry, nq * 8));
-      ws.q_entry_cap = nq;
-    }
+    ISL_TRY(ensure(ws, ws.q_entry, ws.q_entry_cap, std::max<uint64_t>(nq, 1) * 2));
     p.q_entry = ws.q_entry;
     p.q_evals = ws.q_entry + nq;
     const size_t dlds = (size_t)((d + 3) / 4 * 4) * 4 + 64;
-    const uint32_t dgrid = (uint32_t)std::min<uint64_t>(nq, 8192);
+    const uint32_t dgrid = (uint32_t)std::min<uint64_t>(nq_grid, 8192);
     switch ((int)idx->cfg.metric) {
       case ISL_METRIC_COSINE: launch_one(hnsw_descent_kernel<ISL_METRIC_COSINE>, dgrid, dlds, st, p); break;
       case ISL_METRIC_EUCLIDEAN: launch_one(hnsw_descent_kernel<ISL_METRIC_EUCLIDEAN>, dgrid, dlds, st, p); break;
@@ -1765,7 +1878,7 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   }
   if (tl) {
   } else if (use_fast) {
-    uint32_t grid = (uint32_t)std::min<uint64_t>(nq, slots);
+    uint32_t grid = (uint32_t)std::min<uint64_t>(nq_grid, slots);
     int S = ef <= 64 ? 1 : ef <= 128 ? 2 : ef <= 256 ? 4 : 8;
     const int metric = (int)idx->cfg.metric;
     switch (S) {
@@ -1775,7 +1888,7 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
       default: launch_fast<8>(metric, grid, fg.lds, st, p); break;
     }
     ISL_HIP(hipGetLastError());
-  } else {
+  } else if (!warm) {
     // every query goes to the exact kernel: redo = [0, nq)
     std::vector<uint32_t> all(nq);
     for (uint64_t i = 0; i < nq; i++) all[i] = (uint32_t)i;
@@ -1785,28 +1898,38 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
     ISL_HIP(hipStreamSynchronize(st));
   }
   if (!tl) {
-    uint32_t grid = (uint32_t)std::min<uint64_t>(nq, ws.exact_slots);
+    uint32_t grid = (uint32_t)std::min<uint64_t>(nq_grid, idx->pool.slots);
     launch_exact((int)idx->cfg.metric, idx->is_hnsw, grid, exact_lds(ef, (uint32_t)d), st, p);
     ISL_HIP(hipGetLastError());
   }
   ISL_HIP(hipEventRecord(ws.ev1, st));
+  ws.st_inflight = st;
+  if (warm) return ISL_OK;
 
   ISL_HIP(hipMemcpyAsync(ws.h_status, ws.status, nq * 4, hipMemcpyDeviceToHost, st));
   ISL_HIP(hipMemcpyAsync(ws.h_ctr, ws.ctr, nq * 16, hipMemcpyDeviceToHost, st));
   ISL_HIP(hipMemcpyAsync(ws.h_head, ws.ticket, 64, hipMemcpyDeviceToHost, st));
-  ws.busy = true;
+  ws.enqueued = true;
   ws.nq_inflight = nq;
+  ws.k_inflight = k;
   ws.fast_inflight = use_fast;
-  ws.st_inflight = st;
   return ISL_OK;
 }
 
-// Waits for the call in flight on `ws`, folds its counters into the index statistics and turns
-// per-query failures into the CoreError the reference's sequential map would have returned.
+// counters of the most recent call this thread completed, per index (isl_search_last_stats)
+struct LastStats { const isl_index* idx = nullptr; isl_search_stats st{}; };
+thread_local LastStats tl_last_stats;
+void note_last_stats(const isl_index* idx, const isl_search_stats& st) {
+  tl_last_stats.idx = idx;
+  tl_last_stats.st = st;
+}
+
+// Waits for the call in flight on `ws`, leaves its counters in ws.stats and turns per-query
+// failures into the CoreError the reference's sequential map would have returned.
 isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws, uint32_t* misses = nullptr,
                          bool* window_short = nullptr) {
-  if (!ws.busy) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "no search in flight for this token");
-  ws.busy = false;
+  if (!ws.enqueued) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "no search in flight for this token");
+  ws.enqueued = false;
   const uint64_t nq = ws.nq_inflight;
   const bool use_fast = ws.fast_inflight;
   ISL_HIP(hipStreamSynchronize(ws.st_inflight));
@@ -1818,12 +1941,13 @@ isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws, uint32_
   float ms = 0.0f;
   (void)hipEventElapsedTime(&ms, ws.ev0, ws.ev1);
 
-  isl_search_stats& ss = idx->stats;
+  isl_search_stats& ss = ws.stats;
   ss = isl_search_stats{};
   ss.queries = nq;
   ss.exact_path = head[1];
   ss.replayed = head[3];
   ss.kernel_ms = ms;
+  ss.allocations = ws.alloc_events - ws.alloc_mark;
   for (uint64_t i = 0; i < nq; i++) {
     ss.expansions += ctr[i * 4 + 0];
     ss.edges += ctr[i * 4 + 1];
@@ -1919,12 +2043,27 @@ __global__ __launch_bounds__(64) void row_norm2_list_kernel(const float* __restr
   }
 }
 
-// One synchronous search.  With the in-memory provider: enqueue + finish.  With the recompute
-// provider: rounds of (search; every query that needs an absent row reports it and stops) ->
-// (encode the reported nodes once each) until a round completes without a miss; that last round
-// is an ordinary search over materialised rows, so ids, distances, counters and error behaviour
-// are those of the in-memory provider holding the same embeddings.  Re-running the batch per
-// round costs traversal time only, which is noise next to the encoder (5.5 GFLOP per node).
+isl_status prepare_recompute(isl::SearchWorkspace& ws, uint64_t nq) {
+  const uint64_t cap = std::min<uint64_t>(nq * 64 + 64, 0xFFFFFFF0ull);
+  if (ws.miss_cap < cap) {
+    void* ptrs[] = {ws.miss, ws.uniq, ws.uniq_count};
+    for (void* q : ptrs)
+      if (q) (void)hipFree(q);
+    ws.miss = ws.uniq = ws.uniq_count = nullptr;
+    ws.miss_cap = 0;
+    ISL_TRY(lane_malloc(ws, ws.miss, cap * 4));
+    ISL_TRY(lane_malloc(ws, ws.uniq, cap * 4));
+    ISL_TRY(lane_malloc(ws, ws.uniq_count, 4));
+    ws.miss_cap = cap;
+  }
+  return ISL_OK;
+}
+
+// One synchronous search on a claimed lane.  With the in-memory provider: enqueue + finish.  With
+// the recompute provider: rounds of (search; every query that needs an absent row reports it and
+// stops) -> (encode the reported nodes once each) until a round completes without a miss; that
+// last round is an ordinary search over materialised rows, so ids, distances, counters and error
+// behaviour are those of the in-memory provider holding the same embeddings.
 isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const float* d_queries,
                        uint64_t nq, uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_ids,
                        float* d_dist, uint32_t* d_count, hipStream_t user_stream, StreamMode mode,
@@ -1942,30 +2081,23 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
       return st;
     }
   }
-  const uint64_t cap = std::min<uint64_t>(nq * 64 + 64, 0xFFFFFFF0ull);
-  if (ws.miss_cap < cap) {
-    void* ptrs[] = {ws.miss, ws.uniq, ws.uniq_count};
-    for (void* q : ptrs)
-      if (q) (void)hipFree(q);
-    ws.miss = ws.uniq = ws.uniq_count = nullptr;
-    ws.miss_cap = 0;
-    ISL_HIP(hipMalloc(&ws.miss, cap * 4));
-    ISL_HIP(hipMalloc(&ws.uniq, cap * 4));
-    ISL_HIP(hipMalloc(&ws.uniq_count, 4));
-    ws.miss_cap = cap;
-  }
-  hipStream_t st = mode == StreamMode::USER ? user_stream : ws.stream;
-  if (!idx->keep_rows) ISL_HIP(hipMemsetAsync(idx->d_present, 0, idx->present_words * 4, st));
+  // the rounds rewrite the provider's row table and presence bitmap: one recompute search at a time
+  std::lock_guard<std::mutex> rlock(idx->recompute_mu);
+  ISL_TRY(prepare_recompute(ws, nq));
+  ISL_TRY(ensure_lane_stream(ws));
+  if (!idx->keep_rows)
+    ISL_HIP(hipMemsetAsync(idx->d_present, 0, idx->present_words * 4, mode == StreamMode::USER ? user_stream : ws.stream));
   uint64_t encoded = 0, rounds = 0;
   double kernel_ms = 0.0;
   for (;;) {
     ISL_TRY(search_enqueue(idx, ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, user_stream, mode, tl));
+    hipStream_t st = mode == StreamMode::USER ? user_stream : ws.stream;
     uint32_t misses = 0;
     bool window_short = false;
     const isl_status fst = search_finish(idx, ws, &misses, tl ? &window_short : nullptr);
     if (fst == ISL_ERR_SEARCH && window_short && tcall.window_scale < 64) { tcall.window_scale *= 4; continue; }
     ISL_TRY(fst);
-    kernel_ms += idx->stats.kernel_ms;
+    kernel_ms += ws.stats.kernel_ms;
     rounds += 1;
     if (!misses) break;
     if (misses > ws.miss_cap) misses = (uint32_t)ws.miss_cap;
@@ -1983,9 +2115,10 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
     ISL_HIP(hipGetLastError());
     encoded += nu;
   }
-  idx->stats.encoded_nodes = encoded;
-  idx->stats.recompute_rounds = rounds;
-  idx->stats.kernel_ms = kernel_ms;
+  ws.stats.encoded_nodes = encoded;
+  ws.stats.recompute_rounds = rounds;
+  ws.stats.kernel_ms = kernel_ms;
+  ws.stats.allocations = ws.alloc_events - ws.alloc_mark;
   return ISL_OK;
 }
 
@@ -2041,15 +2174,193 @@ __global__ void check_codes_kernel(const uint16_t* __restrict__ codes, uint64_t 
   if (bad) atomicOr(flag, 1u);
 }
 
+// ---- lanes: claimed under idx->mu, then owned by the caller until released ----
+isl::SearchWorkspace* claim_lane(const isl_index* idx) {
+  std::lock_guard<std::mutex> lock(idx->mu);
+  for (auto& w : idx->ws)
+    if (!w.busy) {
+      w.busy = true;
+      w.waiting = false;
+      w.enqueued = false;
+      w.token = 0;
+      w.alloc_mark = w.alloc_events;
+      w.u_ids = nullptr; w.u_dist = nullptr; w.u_count = nullptr;
+      return &w;
+    }
+  return nullptr;
+}
+void release_lane(const isl_index* idx, isl::SearchWorkspace& ws) {
+  std::lock_guard<std::mutex> lock(idx->mu);
+  ws.busy = false;
+  ws.waiting = false;
+  ws.token = 0;
+}
+isl_status no_lane() {
+  return isl::fail(ISL_ERR_SEARCH, "Search error: %d searches already in flight; isl_search_wait one first",
+                   isl::kSearchLanes);
+}
+// RAII: the lane goes back unless a token took it over
+struct LaneGuard {
+  const isl_index* idx;
+  isl::SearchWorkspace* ws;
+  ~LaneGuard() { if (ws) release_lane(idx, *ws); }
+  void keep() { ws = nullptr; }
+};
+
+// host-pointer calls: queries through the pinned buffer to the device ...
+isl_status host_stage_in(isl::SearchWorkspace& ws, const float* queries, uint64_t nq, uint64_t d, uint64_t k) {
+  ISL_TRY(prepare_host_staging(ws, nq, d, k));
+  ISL_TRY(ensure_lane_stream(ws));
+  memcpy(ws.h_q, queries, nq * d * 4);
+  ISL_HIP(hipMemcpyAsync(ws.q_stage, ws.h_q, nq * d * 4, hipMemcpyHostToDevice, ws.stream));
+  return ISL_OK;
+}
+// ... and the answers back into the pinned mirrors (enqueued behind the search kernels)
+isl_status host_stage_out(isl::SearchWorkspace& ws, uint64_t nq, uint64_t k) {
+  if (k) {
+    ISL_HIP(hipMemcpyAsync(ws.h_ids, ws.ids_stage, nq * k * 8, hipMemcpyDeviceToHost, ws.stream));
+    ISL_HIP(hipMemcpyAsync(ws.h_dist, ws.dist_stage, nq * k * 4, hipMemcpyDeviceToHost, ws.stream));
+  }
+  ISL_HIP(hipMemcpyAsync(ws.h_count, ws.count_stage, nq * 4, hipMemcpyDeviceToHost, ws.stream));
+  return ISL_OK;
+}
+void host_copy_out(const isl::SearchWorkspace& ws, uint64_t nq, uint64_t k, uint64_t* out_ids, float* out_dist,
+                   uint32_t* out_count) {
+  if (k) {
+    memcpy(out_ids, ws.h_ids, nq * k * 8);
+    memcpy(out_dist, ws.h_dist, nq * k * 4);
+  }
+  memcpy(out_count, ws.h_count, nq * 4);
+}
+
 }  // namespace
+
+namespace isl {
+
+bool any_lane_busy(const isl_index* idx) {
+  for (const auto& w : idx->ws)
+    if (w.busy) return true;
+  return false;
+}
+
+void free_exact_pool(ExactPool& pl) {
+  void* ptrs[] = {pl.cand_d, pl.cand_id, pl.vis_bits, pl.ulist, pl.locks};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  pl = ExactPool{};
+}
+
+// padded copy of the adjacency (64 ids per node + a degree array): 260 bytes per node buy the
+// traversal one dependent memory round trip per hop.  Built where the CSR becomes resident
+// (isl_index_upload, isl_index_from_device_csr, isl_index_prepare); the handle's fields are set
+// only once the copy is complete.  Not enough memory -> the searches stay on the CSR.
+isl_status ensure_padded_adjacency(isl_index* idx) {
+  if (idx->d_ell || !idx->d_off || !idx->num_nodes || idx->max_degree > 64) return ISL_OK;
+  const uint64_t n = idx->num_nodes;
+  uint32_t* ell = nullptr;
+  uint32_t* deg = nullptr;
+  if (hipMalloc(&ell, n * 64 * 4) != hipSuccess || hipMalloc(&deg, n * 4) != hipSuccess) {
+    (void)hipGetLastError();
+    if (ell) (void)hipFree(ell);
+    return ISL_OK;
+  }
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, nullptr, idx->d_off, idx->d_adj, n,
+                     ell, deg);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    (void)hipFree(ell);
+    (void)hipFree(deg);
+    return fail(ISL_ERR_DEVICE, "padded adjacency: %s", hipGetErrorString(e));
+  }
+  idx->d_ell = ell;
+  idx->d_ell_deg = deg;
+  idx->ell_w = 64;
+  idx->ell_owned = true;
+  return ISL_OK;
+}
+
+isl_status search_device_sync(const isl_index* idx, const float* d_queries, uint64_t nq, uint64_t d,
+                              uint64_t k, uint64_t ef, uint64_t* d_ids, float* d_dist,
+                              uint32_t* d_count, hipStream_t stream) {
+  SearchWorkspace* ws = claim_lane(idx);
+  if (!ws) return no_lane();
+  LaneGuard guard{idx, ws};
+  return search_sync(idx, *ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, stream, StreamMode::USER);
+}
+
+}  // namespace isl
 
 extern "C" {
 
-// picks a lane with no call in flight (under idx->mu)
-static isl::SearchWorkspace* free_lane(const isl_index* idx) {
-  for (auto& w : idx->ws)
-    if (!w.busy) return &w;
-  return nullptr;
+isl_status isl_index_prepare(isl_index* idx, uint64_t max_nq, uint64_t max_ef, uint64_t max_k, int32_t lanes) {
+  if (!idx) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "index is NULL");
+  if (idx->device < 0 || !idx->d_off)
+    return isl::fail(ISL_ERR_DEVICE, "index is not resident on a device (isl_index_upload)");
+  if (!idx->d_emb && !idx->d_emb16)
+    return isl::fail(ISL_ERR_EMBEDDING, "Embedding error: no embedding provider attached");
+  if (lanes < 1 || lanes > isl::kSearchLanes)
+    return isl::fail(ISL_ERR_INVALID_ARGUMENT, "lanes must be 1..%d", isl::kSearchLanes);
+  if (max_nq == 0 || max_nq > 0x7FFFFFFFull) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "max_nq out of range");
+  max_ef = std::max<uint64_t>(std::max(max_ef, max_k), 1);
+  if (max_ef > kMaxExactEf)
+    return isl::fail(ISL_ERR_UNSUPPORTED, "ef = %llu exceeds the device limit %u", (unsigned long long)max_ef,
+                     kMaxExactEf);
+  ISL_TRY(isl::use_device(idx->device));
+  const uint64_t d = idx->emb_d;
+  {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (isl::any_lane_busy(idx))
+      return isl::fail(ISL_ERR_SEARCH, "Search error: isl_index_prepare while searches are in flight");
+    ISL_TRY(isl::ensure_padded_adjacency(idx));
+    ISL_TRY(ensure_pool(idx, idx->ws[0]));
+    // the lanes are held for the duration: the last step exercises them together
+    for (int i = 0; i < lanes; ++i) idx->ws[i].busy = true;
+  }
+  const int ncu = isl::device_cu_count(idx->device);
+  // a smaller ef puts more waves on a CU: size the per-wave overflow tables for the most there can be
+  const uint32_t ovf_slots = (uint32_t)std::min<uint64_t>(max_nq, (uint64_t)ncu * waves_per_cu_cap());
+  struct ReleaseAll {
+    isl_index* idx; int lanes;
+    ~ReleaseAll() { for (int i = 0; i < lanes; ++i) release_lane(idx, idx->ws[i]); }
+  } release_all{idx, lanes};
+  for (int i = 0; i < lanes; ++i) {
+    isl::SearchWorkspace& ws = idx->ws[i];
+    ISL_TRY(prepare_workspace(ws, (uint32_t)max_nq, ovf_slots, push_log_cap((uint32_t)max_ef)));
+    ISL_TRY(prepare_host_staging(ws, max_nq, d, std::max<uint64_t>(max_k, 1)));
+    if (idx->recompute) ISL_TRY(prepare_recompute(ws, max_nq));
+    if (idx->is_hnsw) ISL_TRY(ensure(ws, ws.q_entry, ws.q_entry_cap, max_nq * 2));
+    if (idx->pq && idx->d_codes && !idx->is_hnsw && d == idx->pq->dimension)
+      ISL_TRY(ensure(ws, ws.tl_tables, ws.tl_tables_cap, max_nq * idx->pq->m * idx->pq->K));
+    memset(ws.h_q, 0, max_nq * d * 4);
+  }
+  // The kernels this index will launch, over zero queries, and one staged copy each way, on all
+  // lanes AT ONCE and twice over: code objects loaded, every stream's hardware queue and copy
+  // queue up, the LDS opt-in attribute set, and the runtime's pools of completion signals grown to
+  // what `lanes` calls in flight need (the runtime grows them one concurrent copy at a time, at
+  // several milliseconds each -- measured inside the first calls otherwise).
+  for (int round = 0; round < 2; ++round) {
+    for (int i = 0; i < lanes; ++i) {
+      isl::SearchWorkspace& ws = idx->ws[i];
+      ISL_HIP(hipMemcpyAsync(ws.q_stage, ws.h_q, max_nq * d * 4, hipMemcpyHostToDevice, ws.stream));
+      const uint64_t efs[] = {max_ef, std::min<uint64_t>(max_ef, 64)};
+      for (uint64_t e : efs)
+        ISL_TRY(search_enqueue(idx, ws, nullptr, 0, d, std::min<uint64_t>(max_k, e), e, nullptr, nullptr, nullptr,
+                               nullptr, StreamMode::OWN, nullptr, true));
+      if (idx->pq && idx->d_codes && !idx->is_hnsw && d == idx->pq->dimension) {
+        const TwoLevelCall tl{0.5f};
+        ISL_TRY(search_enqueue(idx, ws, nullptr, 0, d, std::min<uint64_t>(max_k, max_ef), max_ef, nullptr, nullptr,
+                               nullptr, nullptr, StreamMode::OWN, &tl, true));
+      }
+      ISL_HIP(hipMemcpyAsync(ws.h_status, ws.status, max_nq * 4, hipMemcpyDeviceToHost, ws.stream));
+      ISL_HIP(hipMemcpyAsync(ws.h_ctr, ws.ctr, max_nq * 16, hipMemcpyDeviceToHost, ws.stream));
+      ISL_HIP(hipMemcpyAsync(ws.h_head, ws.ticket, 64, hipMemcpyDeviceToHost, ws.stream));
+      ISL_TRY(host_stage_out(ws, max_nq, std::max<uint64_t>(max_k, 1)));
+    }
+    for (int i = 0; i < lanes; ++i) ISL_HIP(hipStreamSynchronize(idx->ws[i].stream));
+  }
+  for (int i = 0; i < lanes; ++i) idx->ws[i].alloc_mark = idx->ws[i].alloc_events;
+  return ISL_OK;
 }
 
 isl_status isl_search_batch_device(const isl_index* idx, const float* d_queries, uint64_t nq,
@@ -2061,11 +2372,13 @@ isl_status isl_search_batch_device(const isl_index* idx, const float* d_queries,
   if (!d_queries || !d_out_count || (k && (!d_out_ids || !d_out_dist)))
     return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
   ISL_TRY(isl::use_device(idx->device));
-  std::lock_guard<std::mutex> lock(idx->mu);
-  isl::SearchWorkspace* ws = free_lane(idx);
-  if (!ws) return isl::fail(ISL_ERR_SEARCH, "Search error: every search lane has a call in flight");
-  return search_sync(idx, *ws, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count,
-                     (hipStream_t)stream, StreamMode::USER);
+  isl::SearchWorkspace* ws = claim_lane(idx);
+  if (!ws) return no_lane();
+  LaneGuard guard{idx, ws};
+  const isl_status st = search_sync(idx, *ws, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count,
+                                    (hipStream_t)stream, StreamMode::USER);
+  note_last_stats(idx, ws->stats);
+  return st;
 }
 
 isl_status isl_search_batch_device_async(const isl_index* idx, const float* d_queries, uint64_t nq,
@@ -2082,28 +2395,75 @@ isl_status isl_search_batch_device_async(const isl_index* idx, const float* d_qu
   ISL_TRY(isl::use_device(idx->device));
   if (idx->recompute)
     return isl::fail(ISL_ERR_UNSUPPORTED, "the recompute provider answers synchronously: use isl_search_batch_device");
-  std::lock_guard<std::mutex> lock(idx->mu);
-  isl::SearchWorkspace* ws = free_lane(idx);
-  if (!ws)
-    return isl::fail(ISL_ERR_SEARCH,
-                     "Search error: %d searches already in flight; isl_search_wait one first",
-                     isl::kSearchLanes);
+  isl::SearchWorkspace* ws = claim_lane(idx);
+  if (!ws) return no_lane();
+  LaneGuard guard{idx, ws};
   ISL_TRY(search_enqueue(idx, *ws, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count,
                          (hipStream_t)stream, StreamMode::OWN_AFTER_USER));
-  ws->token = idx->next_token++;
-  *token = ws->token;
+  {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    ws->token = idx->next_token++;
+    *token = ws->token;
+  }
+  guard.keep();
   return ISL_OK;
 }
 
-isl_status isl_search_wait(const isl_index* idx, uint64_t token) {
-  if (!idx) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "index is NULL");
-  if (token == 0) return ISL_OK;
+isl_status isl_search_batch_async(const isl_index* idx, const float* queries, uint64_t nq, uint64_t d,
+                                  uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dist,
+                                  uint32_t* out_count, uint64_t* token) {
+  if (!token) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "token is NULL");
+  *token = 0;
+  int done = 0;
+  ISL_TRY(precheck(idx, nq, d, k, out_count, false, &done));
+  if (done == 1) return ISL_OK;
+  if (!queries || !out_count || (k && (!out_ids || !out_dist)))
+    return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
   ISL_TRY(isl::use_device(idx->device));
-  std::lock_guard<std::mutex> lock(idx->mu);
-  for (auto& w : idx->ws)
-    if (w.busy && w.token == token) return search_finish(idx, w);
-  return isl::fail(ISL_ERR_INVALID_ARGUMENT, "unknown or already completed search token");
+  if (idx->recompute)
+    return isl::fail(ISL_ERR_UNSUPPORTED, "the recompute provider answers synchronously: use isl_search_batch");
+  isl::SearchWorkspace* ws = claim_lane(idx);
+  if (!ws) return no_lane();
+  LaneGuard guard{idx, ws};
+  ISL_TRY(host_stage_in(*ws, queries, nq, d, k));
+  ISL_TRY(search_enqueue(idx, *ws, ws->q_stage, nq, d, k, ef, ws->ids_stage, ws->dist_stage, ws->count_stage,
+                         nullptr, StreamMode::OWN));
+  ISL_TRY(host_stage_out(*ws, nq, k));
+  ws->u_ids = out_ids;
+  ws->u_dist = out_dist;
+  ws->u_count = out_count;
+  {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    ws->token = idx->next_token++;
+    *token = ws->token;
+  }
+  guard.keep();
+  return ISL_OK;
 }
+
+isl_status isl_search_wait_stats(const isl_index* idx, uint64_t token, isl_search_stats* stats) {
+  if (!idx) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "index is NULL");
+  if (token == 0) {
+    if (stats) *stats = isl_search_stats{};
+    return ISL_OK;
+  }
+  ISL_TRY(isl::use_device(idx->device));
+  isl::SearchWorkspace* ws = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    for (auto& w : idx->ws)
+      if (w.busy && w.token == token && !w.waiting) { ws = &w; w.waiting = true; break; }
+  }
+  if (!ws) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "unknown or already completed search token");
+  LaneGuard guard{idx, ws};
+  const isl_status st = search_finish(idx, *ws);  // the D2H result copies sit on the same stream
+  if (st == ISL_OK && ws->u_count) host_copy_out(*ws, ws->nq_inflight, ws->k_inflight, ws->u_ids, ws->u_dist, ws->u_count);
+  if (stats) *stats = ws->stats;
+  note_last_stats(idx, ws->stats);
+  return st;
+}
+
+isl_status isl_search_wait(const isl_index* idx, uint64_t token) { return isl_search_wait_stats(idx, token, nullptr); }
 
 // host-pointer entry: stage the queries, search on the lane's stream, copy the answers back
 static isl_status search_batch_host(const isl_index* idx, const float* queries, uint64_t nq, uint64_t d,
@@ -2116,38 +2476,18 @@ static isl_status search_batch_host(const isl_index* idx, const float* queries, 
   if (!queries || !out_count || (k && (!out_ids || !out_dist)))
     return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
   ISL_TRY(isl::use_device(idx->device));
-  std::lock_guard<std::mutex> lock(idx->mu);
-  isl::SearchWorkspace* wsp = free_lane(idx);
-  if (!wsp) return isl::fail(ISL_ERR_SEARCH, "Search error: every search lane has a call in flight");
+  isl::SearchWorkspace* wsp = claim_lane(idx);
+  if (!wsp) return no_lane();
+  LaneGuard guard{idx, wsp};
   isl::SearchWorkspace& ws = *wsp;
-  uint64_t qbytes = nq * d * 4;
-  if (ws.q_stage_bytes < qbytes) {
-    if (ws.q_stage) (void)hipFree(ws.q_stage);
-    ws.q_stage = nullptr;
-    ws.q_stage_bytes = 0;
-    ISL_HIP(hipMalloc(&ws.q_stage, qbytes));
-    ws.q_stage_bytes = qbytes;
-  }
-  uint64_t slots = nq * std::max<uint64_t>(k, 1);
-  if (ws.out_stage_slots < slots) {
-    void* ptrs[] = {ws.ids_stage, ws.dist_stage, ws.count_stage};
-    for (void* q : ptrs)
-      if (q) (void)hipFree(q);
-    ws.ids_stage = nullptr; ws.dist_stage = nullptr; ws.count_stage = nullptr;
-    ws.out_stage_slots = 0;
-    ISL_HIP(hipMalloc(&ws.ids_stage, slots * 8));
-    ISL_HIP(hipMalloc(&ws.dist_stage, slots * 4));
-    ISL_HIP(hipMalloc(&ws.count_stage, slots * 4));
-    ws.out_stage_slots = slots;
-  }
-  ISL_HIP(hipMemcpy(ws.q_stage, queries, qbytes, hipMemcpyHostToDevice));
-  ISL_TRY(search_sync(idx, ws, ws.q_stage, nq, d, k, ef, ws.ids_stage, ws.dist_stage, ws.count_stage,
-                      nullptr, StreamMode::OWN, tl));
-  if (k) {
-    ISL_HIP(hipMemcpy(out_ids, ws.ids_stage, nq * k * 8, hipMemcpyDeviceToHost));
-    ISL_HIP(hipMemcpy(out_dist, ws.dist_stage, nq * k * 4, hipMemcpyDeviceToHost));
-  }
-  ISL_HIP(hipMemcpy(out_count, ws.count_stage, nq * 4, hipMemcpyDeviceToHost));
+  ISL_TRY(host_stage_in(ws, queries, nq, d, k));
+  const isl_status st = search_sync(idx, ws, ws.q_stage, nq, d, k, ef, ws.ids_stage, ws.dist_stage, ws.count_stage,
+                                    nullptr, StreamMode::OWN, tl);
+  note_last_stats(idx, ws.stats);
+  ISL_TRY(st);
+  ISL_TRY(host_stage_out(ws, nq, k));
+  ISL_HIP(hipStreamSynchronize(ws.stream));
+  host_copy_out(ws, nq, k, out_ids, out_dist, out_count);
   return ISL_OK;
 }
 
@@ -2168,6 +2508,8 @@ isl_status isl_index_set_pq_codes(isl_index* idx, const isl_pq* pq, const uint16
   if (n > 0x7FFFFFFFull) return isl::fail(ISL_ERR_UNSUPPORTED, "more than 2^31 - 1 code rows");
   ISL_TRY(isl::use_device(idx->device));
   std::lock_guard<std::mutex> lock(idx->mu);
+  if (isl::any_lane_busy(idx))
+    return isl::fail(ISL_ERR_SEARCH, "Search error: PQ codes cannot be swapped while searches are in flight");
   if (idx->d_codes) { (void)hipFree(idx->d_codes); idx->d_codes = nullptr; }
   idx->pq = nullptr;
   idx->ncodes = 0;
@@ -2212,12 +2554,14 @@ isl_status isl_search_two_level_batch_device(const isl_index* idx, const float* 
   if (!d_queries || !d_out_count || (k && (!d_out_ids || !d_out_dist)))
     return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
   ISL_TRY(isl::use_device(idx->device));
-  std::lock_guard<std::mutex> lock(idx->mu);
-  isl::SearchWorkspace* ws = free_lane(idx);
-  if (!ws) return isl::fail(ISL_ERR_SEARCH, "Search error: every search lane has a call in flight");
+  isl::SearchWorkspace* ws = claim_lane(idx);
+  if (!ws) return no_lane();
+  LaneGuard guard{idx, ws};
   const TwoLevelCall tl{rerank_ratio};
-  return search_sync(idx, *ws, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count,
-                     (hipStream_t)stream, StreamMode::USER, &tl);
+  const isl_status st = search_sync(idx, *ws, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count,
+                                    (hipStream_t)stream, StreamMode::USER, &tl);
+  note_last_stats(idx, ws->stats);
+  return st;
 }
 
 isl_status isl_search(const isl_index* idx, const float* query, uint64_t d, uint64_t k,
@@ -2229,20 +2573,8 @@ isl_status isl_search(const isl_index* idx, const float* query, uint64_t d, uint
 
 isl_status isl_search_last_stats(const isl_index* idx, isl_search_stats* out) {
   if (!idx || !out) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL argument");
-  std::lock_guard<std::mutex> lock(idx->mu);
-  *out = idx->stats;
+  *out = tl_last_stats.idx == idx ? tl_last_stats.st : isl_search_stats{};
   return ISL_OK;
 }
 
 }  // extern "C"
-
-namespace isl {
-isl_status search_device_sync(const isl_index* idx, const float* d_queries, uint64_t nq, uint64_t d,
-                              uint64_t k, uint64_t ef, uint64_t* d_ids, float* d_dist,
-                              uint32_t* d_count, hipStream_t stream) {
-  std::lock_guard<std::mutex> lock(idx->mu);
-  isl::SearchWorkspace* ws = free_lane(idx);
-  if (!ws) return isl::fail(ISL_ERR_SEARCH, "Search error: every search lane has a call in flight");
-  return search_sync(idx, *ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, stream, StreamMode::USER);
-}
-}  // namespace isl

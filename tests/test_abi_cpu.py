@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, missing
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
-    assert lib.isl_abi_version() == 1
+    assert lib.isl_abi_version() == 2
 
 
 def test_config_presets():  # leann.rs:1091-1143
@@ -94,6 +94,24 @@ def test_bincode_layout_and_roundtrip():  # leann.rs:1347-1384 + SURVEY 8f-2 lay
         with pytest.raises(ia.CoreError) as ei:
             ia.LeannIndex.from_bytes(b[:cut])
         assert ei.value.kind == "Deserialization"
+
+
+def test_from_bytes_rejects_wrapping_lengths():
+    """Crafted input: num_nodes = 2^64 - 1 makes num_nodes + 1 wrap to 0, which an empty
+    node_offsets used to satisfy; a Vec length beyond the buffer must fail, never allocate."""
+    import struct
+    cfg = ia.LeannIndex.with_defaults().to_bytes()[:75]
+    empty_vec = struct.pack("<Q", 0)
+    for num_nodes in ((1 << 64) - 1, 1 << 61, 5):
+        blob = (cfg + empty_vec + empty_vec + empty_vec + b"\x00" + struct.pack("<Q", 0) +
+                struct.pack("<Q", num_nodes) + empty_vec + b"\x00")
+        with pytest.raises(ia.CoreError) as ei:
+            ia.LeannIndex.from_bytes(blob)
+        assert ei.value.kind == "Deserialization"
+    blob = cfg + struct.pack("<Q", (1 << 63) + 7) + b"\x00" * 64
+    with pytest.raises(ia.CoreError) as ei:
+        ia.LeannIndex.from_bytes(blob)
+    assert ei.value.kind == "Deserialization"
 
 
 def test_provider_rules():  # leann.rs:111-120

@@ -10,7 +10,12 @@ import pytest
 import torch
 
 import islands_amd as ia
-from islands_amd import _ffi, synth
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import synth  # noqa: E402  (harness: data, bench graph, ground truth)
+from islands_amd import _ffi  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 

@@ -53,6 +53,19 @@ def test_from_bytes_rejects_bad_input():
     with pytest.raises(ia.CoreError) as e:
         ia.HnswGraph.from_bytes(bytes(bad_key))
     assert e.value.kind == "Deserialization"
+    # lengths that wrap when multiplied: vlen = 2^62 + 1 makes vlen * 4 == 4 and, with
+    # n = 4 nodes, n * vlen == 4 in 64 bits; a node count of 2^61 makes every size check wrap
+    v4 = uniform_vectors(4, 1, 2)
+    wrap = bytearray(hnsw_to_bincode(v4, [[[1], [0], [3], [2]]], [0, 0, 0, 0], 0, 0))
+    wrap[68:76] = struct.pack("<Q", (1 << 62) + 1)   # vector length of the first entry
+    with pytest.raises(ia.CoreError) as e:
+        ia.HnswGraph.from_bytes(bytes(wrap))
+    assert e.value.kind == "Deserialization"
+    huge_n = bytearray(good)
+    huge_n[44:52] = struct.pack("<Q", 1 << 61)
+    with pytest.raises(ia.CoreError) as e:
+        ia.HnswGraph.from_bytes(bytes(huge_n))
+    assert e.value.kind == "Deserialization"
     # an empty graph needs no device
     empty = hnsw_to_bincode(np.zeros((0, 0), np.float32), [[]], [], None, 0, dimension=None)
     g = ia.HnswGraph.from_bytes(empty)

@@ -4,7 +4,8 @@ import os, sys, time
 sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]
 import numpy as np, torch
 import islands_amd as ia
-from islands_amd import synth
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 768
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 4096

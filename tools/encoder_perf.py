@@ -2,7 +2,8 @@ import sys, os, time
 sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]
 import numpy as np
 import islands_amd as ia
-from islands_amd import synth
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 h = int(sys.argv[3]) if len(sys.argv) > 3 else 768

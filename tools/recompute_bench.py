@@ -21,7 +21,8 @@ import numpy as np
 import torch
 
 import islands_amd as ia
-from islands_amd import synth
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import synth
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 

@@ -2,7 +2,8 @@ import sys, os
 sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]
 import numpy as np, torch
 import islands_amd as ia
-from islands_amd import synth
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import synth
 dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000000
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1024

@@ -123,7 +123,7 @@ def brute_force_topk_native(x: torch.Tensor, q: torch.Tensor, k: int, metric: in
     distance blocks + a running top-k), device buffers in and out."""
     import ctypes as C
 
-    from . import _check, _ffi
+    from islands_amd import _check, _ffi
     nq = q.shape[0]
     x, q = x.contiguous(), q.contiguous()
     ids = torch.zeros((nq, k), dtype=torch.int64, device=x.device)

@@ -13,7 +13,8 @@ sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]
 import torch
 
 import islands_amd as ia
-from islands_amd import synth
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import synth
 
 dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
