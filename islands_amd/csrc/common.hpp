@@ -83,6 +83,8 @@ struct SearchWorkspace {
   bool busy = false;           // under isl_index::mu
   bool waiting = false;        // a thread is inside isl_search_wait for this lane (under mu)
   bool enqueued = false;       // kernels of a call are on the stream (owner only)
+  bool ticket_clean = false;   // the work-queue heads are (or will be, in stream order) zero
+  bool publish_results = false; // host-buffer call: the publish kernel also brings the answers home
   uint64_t token = 0;
   uint64_t nq_inflight = 0, k_inflight = 0;
   bool fast_inflight = false;

@@ -1506,6 +1506,36 @@ __global__ void fill_u32_kernel(uint32_t* p, uint64_t n, uint32_t v) {
   for (; i < n; i += stride) p[i] = v;
 }
 
+// The search path moves its small host<->device traffic with kernels that read / write the
+// lane's pinned host buffers directly (they are mapped into the device's address space) instead
+// of hipMemcpyAsync: a call is then kernels and two event records only.  (The runtime's async
+// copies draw completion signals from pools that grow one concurrent copy at a time, several
+// milliseconds each -- measured as 7 ms stalls inside the first dozens of pipelined calls.)
+struct PublishParams {
+  const uint32_t* src[6];
+  uint32_t* dst[6];
+  uint32_t words[6];
+  uint32_t ticket_seg;  // that segment's source is zeroed once copied: the next call's work-queue heads
+};
+__global__ void publish_kernel(PublishParams pp) {
+  const uint32_t seg = blockIdx.y;
+  const uint32_t n = pp.words[seg];
+  const uint32_t* __restrict__ src = pp.src[seg];
+  uint32_t* __restrict__ dst = pp.dst[seg];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    dst[i] = src[i];
+    if (seg == pp.ticket_seg) const_cast<uint32_t*>(src)[i] = 0u;
+  }
+}
+__global__ void copy_u128_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+__global__ void copy_u32_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
 constexpr uint32_t kExactSlots = 32;
 constexpr uint32_t kOvfBits = 15;
 constexpr uint32_t kMaxExactEf = 4096;
@@ -1557,7 +1587,10 @@ isl_status ensure_lane_stream(isl::SearchWorkspace& ws) {
   if (!ws.ev0) { ISL_HIP(hipEventCreate(&ws.ev0)); ws.alloc_events++; }
   if (!ws.ev1) { ISL_HIP(hipEventCreate(&ws.ev1)); ws.alloc_events++; }
   if (!ws.ev_in) { ISL_HIP(hipEventCreateWithFlags(&ws.ev_in, hipEventDisableTiming)); ws.alloc_events++; }
-  if (!ws.ticket) ISL_TRY(lane_malloc(ws, ws.ticket, 64));
+  if (!ws.ticket) {
+    ISL_TRY(lane_malloc(ws, ws.ticket, 64));
+    ws.ticket_clean = false;
+  }
   if (!ws.h_head) ISL_TRY(lane_host_malloc(ws, ws.h_head, 64));
   ws.stream = st;
   return ISL_OK;
@@ -1747,6 +1780,31 @@ isl_status call_geometry(const isl_index* idx, uint64_t d, uint64_t k, uint64_t 
   return ISL_OK;
 }
 
+// status / counters / work-queue heads of the call -> the lane's pinned mirrors, and for a
+// host-buffer call its answers too; one kernel behind the search kernels.
+isl_status publish(isl::SearchWorkspace& ws, uint64_t nq, uint64_t k, hipStream_t st) {
+  PublishParams pp{};
+  uint32_t n = 0;
+  auto seg = [&](const void* src, void* dst, uint64_t words) {
+    pp.src[n] = (const uint32_t*)src; pp.dst[n] = (uint32_t*)dst; pp.words[n] = (uint32_t)words; ++n;
+  };
+  seg(ws.status, ws.h_status, nq);
+  seg(ws.ctr, ws.h_ctr, nq * 4);
+  pp.ticket_seg = n;
+  seg(ws.ticket, ws.h_head, 16);
+  if (ws.publish_results) {
+    seg(ws.count_stage, ws.h_count, nq);
+    if (k) {
+      seg(ws.ids_stage, ws.h_ids, nq * k * 2);
+      seg(ws.dist_stage, ws.h_dist, nq * k);
+    }
+  }
+  hipLaunchKernelGGL(publish_kernel, dim3(16, n), dim3(256), 0, st, pp);
+  ISL_HIP(hipGetLastError());
+  ws.ticket_clean = true;
+  return ISL_OK;
+}
+
 // Enqueues the kernels of one search on a claimed lane; every pointer is a device pointer.
 // warm = true: the same launches over zero queries (isl_index_prepare: loads the code objects and
 // brings the lane's stream up) -- nothing is read or written beyond the ticket words.
@@ -1851,7 +1909,10 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   }
   const uint64_t nq_grid = warm ? 1 : nq;  // a warm launch needs one workgroup to exist
 
-  ISL_HIP(hipMemsetAsync(ws.ticket, 0, 64, st));
+  // the work-queue heads are zero at this point: the publish kernel of the lane's previous call
+  // left them so; only a lane's first call (or one after a failed enqueue) clears them itself
+  if (!ws.ticket_clean) ISL_HIP(hipMemsetAsync(ws.ticket, 0, 64, st));
+  ws.ticket_clean = false;
   ISL_HIP(hipEventRecord(ws.ev0, st));
   if (tl) {
     // build_distance_tables for the whole batch (pq.rs:307-338), then one wave per query
@@ -1906,9 +1967,7 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   ws.st_inflight = st;
   if (warm) return ISL_OK;
 
-  ISL_HIP(hipMemcpyAsync(ws.h_status, ws.status, nq * 4, hipMemcpyDeviceToHost, st));
-  ISL_HIP(hipMemcpyAsync(ws.h_ctr, ws.ctr, nq * 16, hipMemcpyDeviceToHost, st));
-  ISL_HIP(hipMemcpyAsync(ws.h_head, ws.ticket, 64, hipMemcpyDeviceToHost, st));
+  ISL_TRY(publish(ws, nq, k, st));
   ws.enqueued = true;
   ws.nq_inflight = nq;
   ws.k_inflight = k;
@@ -2185,6 +2244,7 @@ isl::SearchWorkspace* claim_lane(const isl_index* idx) {
       w.token = 0;
       w.alloc_mark = w.alloc_events;
       w.u_ids = nullptr; w.u_dist = nullptr; w.u_count = nullptr;
+      w.publish_results = false;
       return &w;
     }
   return nullptr;
@@ -2207,21 +2267,21 @@ struct LaneGuard {
   void keep() { ws = nullptr; }
 };
 
-// host-pointer calls: queries through the pinned buffer to the device ...
+// host-pointer calls: the queries go through the lane's pinned buffer, from where a kernel pulls
+// them into HBM; the answers come back with the publish kernel (ws.publish_results)
 isl_status host_stage_in(isl::SearchWorkspace& ws, const float* queries, uint64_t nq, uint64_t d, uint64_t k) {
   ISL_TRY(prepare_host_staging(ws, nq, d, k));
   ISL_TRY(ensure_lane_stream(ws));
   memcpy(ws.h_q, queries, nq * d * 4);
-  ISL_HIP(hipMemcpyAsync(ws.q_stage, ws.h_q, nq * d * 4, hipMemcpyHostToDevice, ws.stream));
-  return ISL_OK;
-}
-// ... and the answers back into the pinned mirrors (enqueued behind the search kernels)
-isl_status host_stage_out(isl::SearchWorkspace& ws, uint64_t nq, uint64_t k) {
-  if (k) {
-    ISL_HIP(hipMemcpyAsync(ws.h_ids, ws.ids_stage, nq * k * 8, hipMemcpyDeviceToHost, ws.stream));
-    ISL_HIP(hipMemcpyAsync(ws.h_dist, ws.dist_stage, nq * k * 4, hipMemcpyDeviceToHost, ws.stream));
-  }
-  ISL_HIP(hipMemcpyAsync(ws.h_count, ws.count_stage, nq * 4, hipMemcpyDeviceToHost, ws.stream));
+  const uint64_t bytes = nq * d * 4;
+  if (bytes % 16 == 0)
+    hipLaunchKernelGGL(copy_u128_kernel, dim3(256), dim3(256), 0, ws.stream, (const uint4*)ws.h_q, (uint4*)ws.q_stage,
+                       bytes / 16);
+  else
+    hipLaunchKernelGGL(copy_u32_kernel, dim3(256), dim3(256), 0, ws.stream, (const uint32_t*)ws.h_q,
+                       (uint32_t*)ws.q_stage, bytes / 4);
+  ISL_HIP(hipGetLastError());
+  ws.publish_results = true;
   return ISL_OK;
 }
 void host_copy_out(const isl::SearchWorkspace& ws, uint64_t nq, uint64_t k, uint64_t* out_ids, float* out_dist,
@@ -2342,7 +2402,8 @@ isl_status isl_index_prepare(isl_index* idx, uint64_t max_nq, uint64_t max_ef, u
   for (int round = 0; round < 2; ++round) {
     for (int i = 0; i < lanes; ++i) {
       isl::SearchWorkspace& ws = idx->ws[i];
-      ISL_HIP(hipMemcpyAsync(ws.q_stage, ws.h_q, max_nq * d * 4, hipMemcpyHostToDevice, ws.stream));
+      hipLaunchKernelGGL(copy_u128_kernel, dim3(256), dim3(256), 0, ws.stream, (const uint4*)ws.h_q,
+                         (uint4*)ws.q_stage, max_nq * d * 4 / 16);
       const uint64_t efs[] = {max_ef, std::min<uint64_t>(max_ef, 64)};
       for (uint64_t e : efs)
         ISL_TRY(search_enqueue(idx, ws, nullptr, 0, d, std::min<uint64_t>(max_k, e), e, nullptr, nullptr, nullptr,
@@ -2352,10 +2413,8 @@ isl_status isl_index_prepare(isl_index* idx, uint64_t max_nq, uint64_t max_ef, u
         ISL_TRY(search_enqueue(idx, ws, nullptr, 0, d, std::min<uint64_t>(max_k, max_ef), max_ef, nullptr, nullptr,
                                nullptr, nullptr, StreamMode::OWN, &tl, true));
       }
-      ISL_HIP(hipMemcpyAsync(ws.h_status, ws.status, max_nq * 4, hipMemcpyDeviceToHost, ws.stream));
-      ISL_HIP(hipMemcpyAsync(ws.h_ctr, ws.ctr, max_nq * 16, hipMemcpyDeviceToHost, ws.stream));
-      ISL_HIP(hipMemcpyAsync(ws.h_head, ws.ticket, 64, hipMemcpyDeviceToHost, ws.stream));
-      ISL_TRY(host_stage_out(ws, max_nq, std::max<uint64_t>(max_k, 1)));
+      ws.publish_results = true;
+      ISL_TRY(publish(ws, max_nq, std::max<uint64_t>(max_k, 1), ws.stream));
     }
     for (int i = 0; i < lanes; ++i) ISL_HIP(hipStreamSynchronize(idx->ws[i].stream));
   }
@@ -2428,7 +2487,6 @@ isl_status isl_search_batch_async(const isl_index* idx, const float* queries, ui
   ISL_TRY(host_stage_in(*ws, queries, nq, d, k));
   ISL_TRY(search_enqueue(idx, *ws, ws->q_stage, nq, d, k, ef, ws->ids_stage, ws->dist_stage, ws->count_stage,
                          nullptr, StreamMode::OWN));
-  ISL_TRY(host_stage_out(*ws, nq, k));
   ws->u_ids = out_ids;
   ws->u_dist = out_dist;
   ws->u_count = out_count;
@@ -2485,9 +2543,7 @@ static isl_status search_batch_host(const isl_index* idx, const float* queries, 
                                     nullptr, StreamMode::OWN, tl);
   note_last_stats(idx, ws.stats);
   ISL_TRY(st);
-  ISL_TRY(host_stage_out(ws, nq, k));
-  ISL_HIP(hipStreamSynchronize(ws.stream));
-  host_copy_out(ws, nq, k, out_ids, out_dist, out_count);
+  host_copy_out(ws, nq, k, out_ids, out_dist, out_count);  // published with the last round's kernels
   return ISL_OK;
 }
 
