@@ -104,6 +104,55 @@ def cpu_baseline(x, offsets, neighbours, entry, queries, k, ef, budget_s=25.0):
     }
 
 
+def measure_traffic(args):
+    """roofline.traffic for THIS configuration: FETCH_SIZE of the search kernel's dispatches in a
+    child run of this script under rocprofv3 (MI355X_MICROARCH.md, HBM section: the counter is in
+    KiB and tallies every 128-byte request as 64 bytes on gfx950, so bytes = value * 1024 * 2;
+    the factor was re-checked on this kernel's access pattern, profiles/r01_pmc_fetch.json)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        raise RuntimeError("rocprofv3 not found")
+    out = tempfile.mkdtemp(prefix="isl_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--traffic-child", "--gpus", "1", "--steps", "4",
+             "--warmup", "1", "--pipeline", "1", "--nodes", str(args.nodes), "--dim", str(args.dim), "--nq",
+             str(args.nq), "--k", str(args.k), "--ef", str(args.ef), "--per-cluster", str(args.per_cluster),
+             "--row-dtype", args.row_dtype, "--dataset", args.dataset, "--distinct-batches",
+             str(args.distinct_batches), "--no-cpu-baseline", "--no-host-path", "--no-traffic"]
+    cmd = [rp, "--pmc", "FETCH_SIZE", "--kernel-include-regex", "leann_search_fast", "-d", out, "-o", "p",
+           "--output-format", "csv", "--"] + child
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("ISL_TRAFFIC_BYTES", None)
+    try:
+        pr = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+        if pr.returncode != 0 or not files:
+            raise RuntimeError(f"rocprofv3 child rc={pr.returncode}: {pr.stderr.decode(errors='replace')[-200:]}")
+        vals = []
+        with open(files[0]) as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] == "FETCH_SIZE" and "leann_search_fast" in row["Kernel_Name"]:
+                    vals.append(float(row["Counter_Value"]))
+        line = [l for l in pr.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+        child_res = json.loads(line[-1]) if line else {}
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    if len(vals) < 2:
+        raise RuntimeError(f"{len(vals)} profiled dispatches of the search kernel")
+    vals = vals[1:]  # the first launch warms the caches
+    traffic = float(np.mean(vals)) * 1024.0 * 2.0
+    alg = child_res.get("roofline", {}).get("algorithmic_bytes_per_launch")
+    return {"traffic": round(traffic, 0),
+            "traffic_source": f"rocprofv3 --pmc FETCH_SIZE, child run of this configuration, mean of {len(vals)} "
+                              "launches of leann_search_fast, x 1024 x 2 (KiB; gfx950 counts 128-B requests as 64 B)",
+            "traffic_over_algorithmic": round(traffic / alg, 4) if alg else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,7 +168,15 @@ def main():
     ap.add_argument("--row-dtype", choices=["f32", "bf16"], default="f32",
                     help="storage type of the embedding rows (bf16: rows rounded to bf16, stored as "
                          "such, arithmetic still f32 on the widened values; not the headline config)")
+    ap.add_argument("--dataset", choices=["G", "U"], default="G",
+                    help="G: the headline clustered mixture; U: i.i.d. uniform [-1,1) rows as in "
+                         "benches/hnsw_benchmarks.rs:9-14 (SURVEY 8d asks for both; no cluster structure, "
+                         "so recall at ef=128 is whatever the data allows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer pipelined measurement")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not re-run this configuration under rocprofv3 --pmc FETCH_SIZE for roofline.traffic")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-replica", action="store_true",
                     help="multi-GPU shard runs: skip the extra replica-mode measurement")
     ap.add_argument("--distinct-batches", type=int, default=4)
@@ -172,7 +229,11 @@ def main():
 
         # ---------------- setup (untimed): data, graph, index upload, queries, ground truth
         t0 = time.time()
-        x = synth.make_rows(N, d, lo, n_local, per_cluster=args.per_cluster, device=dev)
+        if args.dataset == "U":
+            x = synth.make_uniform(N, d, 42, device=dev)[lo:hi].contiguous() if shard_mode else \
+                synth.make_uniform(N, d, 42, device=dev)
+        else:
+            x = synth.make_rows(N, d, lo, n_local, per_cluster=args.per_cluster, device=dev)
         x16 = None
         if args.row_dtype == "bf16":
             x16 = x.to(torch.bfloat16)       # the stored rows
@@ -205,7 +266,10 @@ def main():
         for b in range(nb_batches):
             # replica mode: every rank answers its own batches; shard mode: same batch on all ranks
             qoff = (b + (rank * nb_batches if (world > 1 and not shard_mode) else 0)) * nq
-            q = synth.make_rows(N, d, qoff, nq, per_cluster=args.per_cluster, device=dev, query=True)
+            if args.dataset == "U":
+                q = synth.make_uniform(nq, d, 43 + qoff, device=dev)
+            else:
+                q = synth.make_rows(N, d, qoff, nq, per_cluster=args.per_cluster, device=dev, query=True)
             qsets.append(q.contiguous())
             ti, td = synth.brute_force_topk_native(x, q, k)  # exact truth: float32 MFMA brute force
             truths.append((ti + lo, td))
@@ -216,14 +280,11 @@ def main():
                  torch.zeros((nq, k), dtype=torch.float32, device=dev),
                  torch.zeros(nq, dtype=torch.int32, device=dev)) for _ in range(depth)]
         if shard_mode:
-            g_ids = torch.zeros((world, nq, k), dtype=torch.int64, device=dev)
-            g_dist = torch.zeros((world, nq, k), dtype=torch.float32, device=dev)
-            g_cnt = torch.zeros((world, nq), dtype=torch.int32, device=dev)
-            m_ids = torch.zeros((nq, k), dtype=torch.int64, device=dev)
-            m_dist = torch.zeros((nq, k), dtype=torch.float32, device=dev)
-            m_src = torch.zeros((nq, k), dtype=torch.int32, device=dev)
-            m_cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
-            id_base = np.array([r * N // world for r in range(world)], dtype=np.uint64)
+            # search -> ONE all-gather of the packed per-shard records -> merge, enqueued without a
+            # host wait (islands_amd/sharded.py); the exchange of a batch overlaps the traversals of
+            # the batches submitted after it
+            from islands_amd.sharded import ShardedSearcher
+            searcher = ShardedSearcher(N, index=idx, device=dev, depth=depth).prepare(nq, k, ef)
             # exact global truth = merge of the per-shard exact top-k (same collective + merge)
             g_truth = []
             for (ti, td) in truths:
@@ -236,33 +297,21 @@ def main():
                 sel = torch.topk(cd, k, dim=1, largest=False).indices
                 g_truth.append(torch.gather(ci, 1, sel))
 
-        import ctypes as C
-        from islands_amd import _ffi
-
         def enqueue(b):
             """One step = one pass of the hot path over one resident query batch."""
             q = qsets[b % nb_batches]
+            if shard_mode:
+                return searcher.submit(q, k, ef)
             o = outs[b % depth]
             return idx.search_batch_device_async(q.data_ptr(), nq, d, k, ef, o[0].data_ptr(),
                                                  o[1].data_ptr(), o[2].data_ptr())
 
         def finish(b, token):
+            if shard_mode:
+                (m_ids, m_dist, m_src, m_cnt), st = searcher.result(token, with_stats=True)
+                return st, (m_ids, m_cnt)
             st = idx.wait_stats(token)  # the counters of exactly this call
             o = outs[b % depth]
-            if shard_mode:
-                # the one exchange step of the path: per-shard top-k over xGMI (RCCL all-gather)
-                all_gather_rows(g_ids.view(world * nq, k), o[0])
-                all_gather_rows(g_dist.view(world * nq, k), o[1])
-                all_gather_rows(g_cnt.view(world * nq), o[2])
-                # no device-wide synchronize here: it would wait for the other searches in flight.
-                # The collectives are ordered on torch's current (= the default) stream, which is
-                # the stream the merge below is launched on.
-                ia._check(_ffi.lib().isl_merge_topk(
-                    world, nq, k, C.c_void_p(g_ids.data_ptr()), C.c_void_p(g_dist.data_ptr()),
-                    C.c_void_p(g_cnt.data_ptr()), id_base.ctypes.data_as(C.c_void_p), k,
-                    C.c_void_p(m_ids.data_ptr()), C.c_void_p(m_dist.data_ptr()),
-                    C.c_void_p(m_src.data_ptr()), C.c_void_p(m_cnt.data_ptr()), 1, local_rank, None))
-                return st, (m_ids, m_cnt)
             return st, (o[0], o[2])
 
         def barrier():
@@ -300,6 +349,8 @@ def main():
         agg, recalls = run(args.warmup, args.steps, True)
         barrier()
         elapsed = time.perf_counter() - t0
+        if shard_mode:
+            searcher.check_flags()
         if world > 1:
             tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -339,8 +390,10 @@ def main():
             "data": "synthetic",
             "recall_at_10": round(recall, 4),
             "config": {
-                "workload": f"{N} x {d} {args.row_dtype} rows resident in HBM (in-memory provider), hierarchical "
-                            f"Gaussian mixture, graph deg<= 60 (mean {gst['deg_mean']:.1f}), "
+                "workload": f"{N} x {d} {args.row_dtype} rows resident in HBM (in-memory provider), "
+                            + ("hierarchical Gaussian mixture" if args.dataset == "G" else
+                               "dataset U: i.i.d. uniform [-1,1) rows (benches/hnsw_benchmarks.rs:9-14)") +
+                            f", graph deg<= 60 (mean {gst['deg_mean']:.1f}), "
                             f"query batch {nq}, k={k}, ef={ef}, cosine",
                 "nodes": N, "dim": d, "query_batch": nq, "k": k, "ef": ef,
                 "parallelism": ("single" if world == 1 else
@@ -369,7 +422,7 @@ def main():
                 "algorithmic_bytes_per_launch": round(bytes_per_launch, 0),
             },
         }
-        if world == 1:
+        if world == 1 and not args.no_host_path and not args.traffic_child:
             # QPS by SURVEY 8(d): host buffers in, host buffers out (the caller contract of
             # search.rs:150-181 / indexer/service.rs:781-785), `depth` calls in flight through
             # isl_search_batch_async -- H2D of the queries and D2H of the answers inside the timed
@@ -420,7 +473,18 @@ def main():
         result["replica_mode"]["parallelism"] = rep["config"]["parallelism"]
         result["replica_mode"]["roofline_frac_per_gpu"] = rep["roofline"]["frac"]
         x = offsets = neighbours = entry = qsets = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_traffic and not args.traffic_child:
+        # HBM bytes per launch of the dominant kernel: this same configuration once more, as a child
+        # process under `rocprofv3 --pmc FETCH_SIZE` (its own pass, kernel trace only), one launch
+        # in flight so that a dispatch's counter is that launch's.  Failure of any kind -> null.
+        try:
+            t0 = time.time()
+            result["roofline"].update(measure_traffic(args))
+            log(f"traffic pass under rocprofv3 took {time.time() - t0:.1f}s")
+        except Exception as e:
+            result["roofline"]["traffic"] = None
+            result["roofline"]["traffic_source"] = f"not measured: {e!r}"[:300]
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.traffic_child:
         try:
             result["cpu_baseline"] = cpu_baseline(x, offsets, neighbours, entry, qsets[0], k, ef)
         except Exception as e:  # the baseline must never take the measured number down with it

@@ -255,6 +255,11 @@ isl_status isl_search_batch_device_async(const isl_index* idx, const float* d_qu
  * receives the counters of exactly that call. */
 isl_status isl_search_wait_stats(const isl_index* idx, uint64_t token, isl_search_stats* stats);
 isl_status isl_search_wait(const isl_index* idx, uint64_t token);
+/* Makes `stream` wait (on the device, no host synchronisation) for the search kernels of the call
+ * `token` names: what a consumer of the device-resident answers enqueues on its own stream -- the
+ * shard exchange of a multi-GPU search issues its all-gather behind this -- while the host keeps
+ * submitting.  The call still has to be completed with isl_search_wait[_stats]. */
+isl_status isl_search_stream_wait(const isl_index* idx, uint64_t token, void* stream);
 /* LeannIndex::search, leann.rs:858-865: one query, ef = config.ef_search. */
 isl_status isl_search(const isl_index* idx, const float* query, uint64_t d, uint64_t k,
                       uint64_t* out_ids, float* out_dist, uint32_t* out_count);
@@ -306,6 +311,18 @@ isl_status isl_merge_topk(uint64_t nlists, uint64_t nq, uint64_t k, const uint64
                           uint64_t top_k, uint64_t* out_ids, float* out_scores,
                           uint32_t* out_src, uint32_t* out_count, int32_t mem, int32_t device,
                           void* stream);
+/* The same merge for the multi-GPU exchange, asynchronous and allocation-free: every
+ * shard's answers arrive as one packed record of `list_stride` bytes -- ids u64[nq][k], then
+ * distances f32[nq][k], then counts u32[nq] (isl_shard_record_bytes) -- which is what one
+ * all-gather delivers in rank order.  Everything lives on the device (d_id_base: u64[nlists]);
+ * the kernel is enqueued on `stream` and nothing is waited for.  *d_flags (u32, zeroed by the
+ * caller once) collects bit 0 = a NaN score met (the reference panics, search.rs:231), bit 1 =
+ * a list was not ascending; read it when the results are consumed. */
+uint64_t isl_shard_record_bytes(uint64_t nq, uint64_t k);
+isl_status isl_merge_topk_packed_async(uint64_t nlists, uint64_t nq, uint64_t k, const void* d_records,
+                                       uint64_t list_stride, const uint64_t* d_id_base, uint64_t top_k,
+                                       uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_src,
+                                       uint32_t* d_out_count, uint32_t* d_flags, int32_t device, void* stream);
 /* Product-level merge, src/indexer/service.rs:775-801 (IndexerService::search_with_embeddings):
  * per list the (id, distance) results of one index (searched with ef = max(top_k, 100), :781);
  * results whose id has no file entry are dropped (`files_len[l]` = stored.files.len(), host

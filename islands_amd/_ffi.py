@@ -100,6 +100,10 @@ SIGNATURES = {
     "isl_search_batch_device_async": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, P(u64)]),
     "isl_search_wait": (i32, [C.c_void_p, u64]),
+    "isl_search_stream_wait": (i32, [C.c_void_p, u64, C.c_void_p]),
+    "isl_shard_record_bytes": (u64, [u64, u64]),
+    "isl_merge_topk_packed_async": (i32, [u64, u64, u64, C.c_void_p, u64, C.c_void_p, u64, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, i32, C.c_void_p]),
     "isl_search_wait_stats": (i32, [C.c_void_p, u64, P(SearchStatsC)]),
     "isl_search_batch_async": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64, C.c_void_p,
                                      C.c_void_p, C.c_void_p, P(u64)]),

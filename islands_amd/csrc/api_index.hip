@@ -2,7 +2,7 @@
 // bincode (de)serialisation, device upload of the CSR graph and of the
 // in-memory embedding provider.  Mirrors src/core/leann.rs of the reference;
 // each function cites the lines it replaces.
-#include "device_common.cuh"
+#include "device_common.hip.h"
 #include "encoder.hpp"
 
 #include <algorithm>

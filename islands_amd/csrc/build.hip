@@ -9,7 +9,7 @@
 // an input because random_level draws from thread_rng, :549-554); with larger batches the
 // searches of a step see the graph as of the step's start and the links of a step are applied
 // under per-row locks in an unspecified order -- a throughput mode, same rules, no parity claim.
-#include "device_common.cuh"
+#include "device_common.hip.h"
 
 #include <algorithm>
 #include <vector>

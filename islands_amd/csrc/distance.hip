@@ -1,7 +1,7 @@
 // Batched distance ops: Distance::{calculate, calculate_squared, batch_calculate}
 // (src/core/distance.rs:22-66) and normalize_vector (distance.rs:125-132) on gfx950.
-// Arithmetic order is the reference's (see device_common.cuh): one lane owns one row.
-#include "device_common.cuh"
+// Arithmetic order is the reference's (see device_common.hip.h): one lane owns one row.
+#include "device_common.hip.h"
 
 #include <algorithm>
 #include <vector>

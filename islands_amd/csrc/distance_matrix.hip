@@ -4,9 +4,9 @@
 // The dot products come out of v_mfma_f32_32x32x2_f32 in the MFMA's accumulation order, so the
 // values agree with the reference's sequential sums to float32 rounding (<= 1e-5 on normalised
 // rows), not bit for bit -- the traversal keeps the exact-order kernels.
-#include "device_common.cuh"
-#include "gemm_f32.cuh"
-#include "gemm_bf16.cuh"
+#include "device_common.hip.h"
+#include "gemm_f32.hip.h"
+#include "gemm_bf16.hip.h"
 
 #include <algorithm>
 #include <vector>

@@ -14,8 +14,8 @@
 // fixed order, so a node's embedding does not depend on what it is batched with.
 #include "common.hpp"
 #include "encoder.hpp"
-#include "gemm_f32.cuh"
-#include "gemm_bf16.cuh"
+#include "gemm_f32.hip.h"
+#include "gemm_bf16.hip.h"
 
 #include <algorithm>
 #include <cmath>

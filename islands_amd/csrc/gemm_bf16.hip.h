@@ -1,14 +1,14 @@
 // bf16-input GEMM on the matrix cores for the encoder's optional reduced-precision mode
 // (isl_encoder_set_precision): C[M,N] = A[M,K] W[N,K]^T + bias (+ GELU, + residual) with A in
 // float32 (rounded to bf16 while it is staged into LDS), W pre-converted to bf16, float32
-// accumulation in v_mfma_f32_32x32x16_bf16.  Same tiling idea as gemm_f32.cuh: 128x128 tile per
+// accumulation in v_mfma_f32_32x32x16_bf16.  Same tiling idea as gemm_f32.hip.h: 128x128 tile per
 // 256-thread workgroup, 64x64 per wave = 2x2 MFMA blocks, K in slabs of 64, the next slab
 // prefetched into registers.  Operand layout of the 32x32x16 MFMA: lane l supplies row (or
 // column) l % 32 and the 8 consecutive k values 8 * (l / 32) .. + 7 of each 16-wide k step.
 #pragma once
 
 #include "common.hpp"
-#include "gemm_f32.cuh"
+#include "gemm_f32.hip.h"
 
 namespace isl_gemm {
 

@@ -11,10 +11,12 @@ namespace {
 // k-way merge that prefers the lowest list on equal scores IS the stable sort of the
 // concatenation.  NaN scores make the reference panic (partial_cmp().unwrap(), search.rs:231):
 // reported through *nan_flag.
+// list l's ids / scores / counts start `lstride` BYTES after list l - 1's (0 = the dense
+// [list][query][k] layout of isl_merge_topk; the packed shard records otherwise)
 __global__ void merge_topk_kernel(uint32_t nlists, uint32_t nq, uint32_t k,
-                                  const uint64_t* __restrict__ ids,
-                                  const float* __restrict__ scores,
-                                  const uint32_t* __restrict__ counts,
+                                  const uint64_t* __restrict__ ids0,
+                                  const float* __restrict__ scores0,
+                                  const uint32_t* __restrict__ counts0, uint64_t lstride,
                                   const uint64_t* __restrict__ id_base, uint32_t top_k,
                                   uint64_t* __restrict__ out_ids, float* __restrict__ out_scores,
                                   uint32_t* __restrict__ out_src, uint32_t* __restrict__ out_count,
@@ -24,16 +26,21 @@ __global__ void merge_topk_kernel(uint32_t nlists, uint32_t nq, uint32_t k,
   // 1.0 - distance, stable sort by score DESCENDING, truncate.
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
+  const uint64_t istr = lstride ? lstride : (uint64_t)nq * k * 8, sstr = lstride ? lstride : (uint64_t)nq * k * 4,
+                 cstr = lstride ? lstride : (uint64_t)nq * 4;
+  auto ids_of = [&](uint32_t l) { return (const uint64_t*)((const char*)ids0 + l * istr) + (uint64_t)q * k; };
+  auto sc_of = [&](uint32_t l) { return (const float*)((const char*)scores0 + l * sstr) + (uint64_t)q * k; };
+  auto cnt_of = [&](uint32_t l) { return *((const uint32_t*)((const char*)counts0 + l * cstr) + q); };
   constexpr uint32_t MAXL = 64;
   uint32_t pos[MAXL];
   uint32_t total = 0;
   bool sorted = true, has_nan = false;
   for (uint32_t l = 0; l < nlists; ++l) {
     pos[l] = 0;
-    uint32_t c = counts[(uint64_t)l * nq + q];
+    uint32_t c = cnt_of(l);
     if (c > k) c = k;
     total += c;
-    const float* sc = scores + ((uint64_t)l * nq + q) * k;
+    const float* sc = sc_of(l);
     for (uint32_t i = 0; i < c; ++i) {
       if (sc[i] != sc[i]) has_nan = true;
       if (i && sc[i] < sc[i - 1]) sorted = false;
@@ -46,12 +53,12 @@ __global__ void merge_topk_kernel(uint32_t nlists, uint32_t nq, uint32_t k,
     int best = -1;
     float bs = 0.0f;
     for (uint32_t l = 0; l < nlists; ++l) {
-      uint32_t c = counts[(uint64_t)l * nq + q];
+      uint32_t c = cnt_of(l);
       if (c > k) c = k;
       if (service && id_base)  // stored.files.get(id) == None -> skipped, service.rs:788
-        while (pos[l] < c && ids[((uint64_t)l * nq + q) * k + pos[l]] >= id_base[l]) pos[l]++;
+        while (pos[l] < c && ids_of(l)[pos[l]] >= id_base[l]) pos[l]++;
       if (pos[l] >= c) continue;
-      float s = scores[((uint64_t)l * nq + q) * k + pos[l]];
+      float s = sc_of(l)[pos[l]];
       if (service) s = 1.0f - s;  // service.rs:791
       if (best < 0 || (service ? s > bs : s < bs)) {  // strict: equal scores keep the earlier list
         best = (int)l;
@@ -59,8 +66,7 @@ __global__ void merge_topk_kernel(uint32_t nlists, uint32_t nq, uint32_t k,
       }
     }
     if (best < 0) break;
-    uint64_t src = ((uint64_t)best * nq + q) * k + pos[best];
-    out_ids[(uint64_t)q * top_k + n] = ids[src] + ((id_base && !service) ? id_base[best] : 0ull);
+    out_ids[(uint64_t)q * top_k + n] = ids_of((uint32_t)best)[pos[best]] + ((id_base && !service) ? id_base[best] : 0ull);
     out_scores[(uint64_t)q * top_k + n] = bs;
     if (out_src) out_src[(uint64_t)q * top_k + n] = (uint32_t)best;
     pos[best]++;
@@ -126,7 +132,7 @@ static isl_status merge_lists(uint32_t service, uint64_t nlists, uint64_t nq, ui
   if (e == hipSuccess) {
     uint32_t blocks = (uint32_t)((nq + 63) / 64);
     hipLaunchKernelGGL(merge_topk_kernel, dim3(blocks), dim3(64), 0, st, (uint32_t)nlists,
-                       (uint32_t)nq, (uint32_t)k, d_ids, d_sc, d_cnt, d_base, (uint32_t)top_k, d_oi,
+                       (uint32_t)nq, (uint32_t)k, d_ids, d_sc, d_cnt, (uint64_t)0, d_base, (uint32_t)top_k, d_oi,
                        d_os, d_osrc, d_oc, d_flags, service);
     e = hipGetLastError();
   }
@@ -170,4 +176,29 @@ extern "C" isl_status isl_merge_service(uint64_t nlists, uint64_t nq, uint64_t k
                                         int32_t mem, int32_t device, void* stream) {
   return merge_lists(1, nlists, nq, k, ids, distances, counts, files_len, top_k, out_ids, out_scores,
                      out_src, out_count, mem, device, stream);
+}
+
+extern "C" uint64_t isl_shard_record_bytes(uint64_t nq, uint64_t k) {
+  return (nq * k * 12 + nq * 4 + 15) / 16 * 16;  // ids | distances | counts, padded to 16 bytes
+}
+
+extern "C" isl_status isl_merge_topk_packed_async(uint64_t nlists, uint64_t nq, uint64_t k, const void* d_records,
+                                                  uint64_t list_stride, const uint64_t* d_id_base,
+                                                  uint64_t top_k, uint64_t* d_out_ids, float* d_out_scores,
+                                                  uint32_t* d_out_src, uint32_t* d_out_count, uint32_t* d_flags,
+                                                  int32_t device, void* stream) {
+  if (nq == 0) return ISL_OK;
+  if (nlists == 0 || nlists > 64) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "nlists must be in [1, 64]");
+  if (!d_records || !d_out_count || !d_flags || (top_k && (!d_out_ids || !d_out_scores)))
+    return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
+  if (list_stride < nq * k * 12 + nq * 4 || list_stride % 8)
+    return isl::fail(ISL_ERR_INVALID_ARGUMENT, "list_stride must cover a record and be a multiple of 8");
+  ISL_TRY(isl::use_device(device));
+  const char* base = (const char*)d_records;
+  hipLaunchKernelGGL(merge_topk_kernel, dim3((uint32_t)((nq + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                     (uint32_t)nlists, (uint32_t)nq, (uint32_t)k, (const uint64_t*)base,
+                     (const float*)(base + nq * k * 8), (const uint32_t*)(base + nq * k * 12), list_stride, d_id_base,
+                     (uint32_t)top_k, d_out_ids, d_out_scores, d_out_src, d_out_count, d_flags, 0u);
+  ISL_HIP(hipGetLastError());
+  return ISL_OK;
 }

@@ -1,8 +1,8 @@
 // Product-quantisation distance ops of src/core/pq.rs on gfx950:
 //   build_distance_tables (pq.rs:307-338), table_distance (:341-348),
 //   asymmetric_distance (:275-304), encode / find_nearest (:221-244, :86-106).
-// Every sum keeps the reference's left-to-right f32 order (device_common.cuh).
-#include "device_common.cuh"
+// Every sum keeps the reference's left-to-right f32 order (device_common.hip.h).
+#include "device_common.hip.h"
 
 #include <algorithm>
 #include <cfloat>

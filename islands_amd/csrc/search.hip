@@ -12,7 +12,7 @@
 //     distance is bit-identical to the Rust scalar loop and every traversal decision (strict
 //     float compares at leann.rs:925,959) matches.  The four lanes of a quad own one row, load 16
 //     of every 64 bytes of it straight from global memory into a register ring and exchange the
-//     products with DPP (device_common.cuh, direct_distances).
+//     products with DPP (device_common.hip.h, direct_distances).
 //   * fast kernel: the result set R (<= ef entries, key = (OrderedFloat d, id)) lives in registers
 //     as a sorted array spread over the wave; the candidate heap is implicit (live candidates are
 //     exactly the unexpanded entries of R); the pushes of a hop are merged into R at once.
@@ -22,7 +22,7 @@
 //   * exact kernel: emulates Rust's BinaryHeap push/pop/into_iter byte for byte (candidates in
 //     HBM scratch, results in LDS) for those queries, for ef > 512, for adjacency rows longer
 //     than 64 and for NaN / -0.0 distances.
-#include "device_common.cuh"
+#include "device_common.hip.h"
 #include "encoder.hpp"
 
 #include <algorithm>
@@ -2522,6 +2522,19 @@ isl_status isl_search_wait_stats(const isl_index* idx, uint64_t token, isl_searc
 }
 
 isl_status isl_search_wait(const isl_index* idx, uint64_t token) { return isl_search_wait_stats(idx, token, nullptr); }
+
+isl_status isl_search_stream_wait(const isl_index* idx, uint64_t token, void* stream) {
+  if (!idx) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "index is NULL");
+  if (token == 0) return ISL_OK;
+  ISL_TRY(isl::use_device(idx->device));
+  std::lock_guard<std::mutex> lock(idx->mu);
+  for (auto& w : idx->ws)
+    if (w.busy && w.token == token) {
+      ISL_HIP(hipStreamWaitEvent((hipStream_t)stream, w.ev1, 0));  // recorded behind the last search kernel
+      return ISL_OK;
+    }
+  return isl::fail(ISL_ERR_INVALID_ARGUMENT, "unknown or already completed search token");
+}
 
 // host-pointer entry: stage the queries, search on the lane's stream, copy the answers back
 static isl_status search_batch_host(const isl_index* idx, const float* queries, uint64_t nq, uint64_t d,

@@ -76,6 +76,34 @@ def test_batched_build_keeps_the_invariants(orc):
     assert (ids[:, 0] == np.arange(0, n, 30)).mean() >= 0.9
 
 
+def test_clustered_rows_build_equals_the_oracle(orc):
+    """The clustered case round 1 took out of the test above: the reference's
+    selection rule keeps the m0 closest candidates without any diversity, so on clustered rows the
+    graph falls apart into its clusters and self-query recall collapses -- in the ORACLE's sequential
+    build of the reference rule just as on the device.  What is asserted is therefore equality: the
+    device builder at batch = 1 returns the oracle's index byte for byte, its searches return the
+    oracle's answers, and its (low) recall is the oracle's recall."""
+    n, d = 1200, 16
+    v = clustered_vectors(n, d, 21)
+    cfg = ia.LeannConfig(m=8, m0=16, ef_construction=64)
+    levels = np.zeros(n, np.uint64)
+    csr = orc.leann_build(v, m=8, m0=16, ef_construction=64, levels=levels)
+    idx = ia.LeannIndex.build(v, cfg, levels=levels, batch=1)
+    g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels,
+                    entry_point=csr.entry_point, max_level=csr.max_level, num_nodes=csr.num_nodes,
+                    degree_counts=csr.degree_counts)
+    assert idx.to_bytes() == ia.LeannIndex.from_csr(g, cfg, dimension=d).to_bytes()
+    q = v[::20]
+    ids, dist, cnt = idx.search_batch(q, 1, 64)
+    hits_dev = hits_orc = 0
+    for i in range(q.shape[0]):
+        r = orc.leann_search(csr, v, q[i], 1, 64)
+        assert ids[i, :int(cnt[i])].tolist() == r.ids.tolist()
+        hits_orc += int(r.ids.size and r.ids[0] == i * 20)
+        hits_dev += int(cnt[i] and ids[i, 0] == i * 20)
+    assert hits_dev == hits_orc
+
+
 def test_build_edge_cases():
     e = ia.LeannIndex.build(np.zeros((0, 0), np.float32))
     assert e.is_empty()

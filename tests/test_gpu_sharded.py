@@ -1,0 +1,108 @@
+"""Two-rank rehearsal of the multi-GPU path on ONE card (gloo rendezvous, both ranks on cuda:0):
+the real HIP shard search writes its packed record in place, ShardedSearcher exchanges the
+records with one all-gather (through host memory here; RCCL over xGMI on a multi-GPU node) and
+isl_merge_topk_packed_async merges them.  Expected = the oracle's MultiIndexSearcher
+(search.rs:211-237) over the same two sub-graphs, ids and f32 bits."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shards(n_total, d, world):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    import oracle as orc
+    from _data import clustered_vectors, knn_graph
+    from islands_amd.sharded import shard_range
+
+    x = clustered_vectors(n_total, d, 5, per_cluster=40)
+    out = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        xs = x[lo:hi]
+        off, nb = knn_graph(xs, 14, seed=7 + r)
+        out.append((lo, xs, orc.Csr(off, nb, entry_point=0)))
+    qs = [clustered_vectors(40, d, 9 + b, per_cluster=3) for b in range(5)]
+    return orc, x, out, qs
+
+
+def _worker(rank, world, port, n_total, d, k, ef, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc, x, shards, qs = _shards(n_total, d, world)
+    import islands_amd as ia
+    from islands_amd.sharded import ShardedSearcher
+
+    torch.cuda.set_device(0)
+    lo, xs, csr = shards[rank]
+    g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels, entry_point=0,
+                    num_nodes=csr.num_nodes, degree_counts=csr.degree_counts)
+    idx = ia.LeannIndex.from_csr(g, dimension=d).upload(0)
+    idx.set_embeddings(xs)
+    s = ShardedSearcher(n_total, index=idx, device="cuda:0", depth=3)
+    s.prepare(qs[0].shape[0], k, ef)
+    assert s.world == world and s.rank == rank
+    dq = [torch.from_numpy(q).cuda() for q in qs]
+    # three batches in flight, then the rest
+    res, handles = [], []
+    for b, q in enumerate(dq):
+        handles.append(s.submit(q, k, ef))
+        if len(handles) == 3:
+            (ids, dd, src, cnt), st = s.result(handles.pop(0), with_stats=True)
+            assert st["allocations"] == 0 and st["queries"] == q.shape[0]
+            res.append((ids.cpu().numpy().copy(), dd.cpu().numpy().copy(), src.cpu().numpy().copy(),
+                        cnt.cpu().numpy().copy()))
+    while handles:
+        ids, dd, src, cnt = s.result(handles.pop(0))
+        res.append((ids.cpu().numpy().copy(), dd.cpu().numpy().copy(), src.cpu().numpy().copy(), cnt.cpu().numpy().copy()))
+    s.check_flags()
+    if rank == 0:
+        torch.save(res, out_path)
+    # every rank holds the same merged answer
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [r[0].tolist() for r in res])
+    assert all(g_ == gathered[0] for g_ in gathered)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_one_card_equal_multi_index_searcher(tmp_path):
+    world, n_total, d, k, ef = 2, 3000, 32, 7, 40
+    out = str(tmp_path / "merged.pt")
+    mp.spawn(_worker, args=(world, _free_port(), n_total, d, k, ef, out), nprocs=world, join=True)
+    res = torch.load(out, weights_only=False)
+    orc, x, shards, qs = _shards(n_total, d, world)
+    for b, q in enumerate(qs):
+        ids_b, dd_b, src_b, cnt_b = res[b]
+        for qi in range(q.shape[0]):
+            li, ls = [], []
+            for (lo, xs, csr) in shards:
+                r = orc.leann_search(csr, xs, q[qi], k, ef)
+                li.append(r.ids + np.uint64(lo))
+                ls.append(r.dist)
+            st, ids, sc, src = orc.multi_index_merge(li, ls, k)
+            n = int(cnt_b[qi])
+            assert n == ids.size
+            assert ids_b[qi, :n].astype(np.uint64).tolist() == ids.tolist(), (b, qi)
+            assert dd_b[qi, :n].view(np.uint32).tolist() == sc.view(np.uint32).tolist()
+            assert src_b[qi, :n].tolist() == src.tolist()
