@@ -123,7 +123,7 @@ isl_status isl_index_from_device_csr(const isl_leann_config* cfg, int32_t device
  * `levels` replaces random_level (thread_rng, :549-554; NULL = all 0).  `batch` = nodes inserted
  * per step: 1 reproduces the reference's sequential construction (CsrGraph identical field by
  * field), larger values trade that for throughput.  The vectors become the index's in-memory
- * provider.  Limits: m0 <= 63, ef_construction <= 512. */
+ * provider.  Limits: m0 <= 128 (LeannConfig::accurate() has 96), ef_construction <= 512. */
 isl_status isl_index_build(const isl_leann_config* cfg, const float* vectors, uint64_t n, uint64_t d,
                            const uint64_t* levels, uint64_t batch, int32_t mem, int32_t device,
                            isl_index** out);

@@ -137,16 +137,41 @@ __global__ __launch_bounds__(64) void link_kernel(BuildParams p) {
         __threadfence_block();
         __syncthreads();
         const float q_norm = load_query<METRIC>(p.emb + (uint64_t)nid * p.stride, p.d, qs);
-        const uint32_t rid = lane < dg ? ((volatile uint32_t*)row)[lane] : 0u;  // W <= 64
-        const float aux = (METRIC == METRIC_COSINE_PRE && lane < dg) ? p.norm2[rid] : 0.0f;
-        const float dist = wave_distances<METRIC>(p.emb, p.stride, p.d, rid, dg, qs, tile, q_norm, aux);
-        uint32_t rank = 0;
-        for (uint32_t i = 0; i < dg; ++i) {
-          const float di = rl_f(dist, (int)i);
-          rank += (di < dist) || (!(dist < di) && !(di < dist) && i < lane);  // stable, `<` only
+        // the row holds dg = m0 + 1 <= 129 ids: up to three slices of 64, one id per lane each
+        constexpr int CH = 3;
+        uint32_t rid[CH];
+        float dist[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const uint32_t base = 64u * c;
+          const uint32_t cnt = dg > base ? (dg - base < 64u ? dg - base : 64u) : 0u;
+          rid[c] = lane < cnt ? ((volatile uint32_t*)row)[base + lane] : 0u;
+          dist[c] = 0.0f;
+          if (cnt) {
+            const float aux = (METRIC == METRIC_COSINE_PRE && lane < cnt) ? p.norm2[rid[c]] : 0.0f;
+            dist[c] = wave_distances<METRIC>(p.emb, p.stride, p.d, rid[c], cnt, qs, tile, q_norm, aux);
+          }
+        }
+        // stable sort by distance (`<` only, leann.rs:650): rank of every entry among all dg
+        uint32_t rank[CH] = {0, 0, 0};
+#pragma unroll
+        for (int ci = 0; ci < CH; ++ci) {
+          const uint32_t basei = 64u * ci;
+          const uint32_t cnti = dg > basei ? (dg - basei < 64u ? dg - basei : 64u) : 0u;
+          for (uint32_t l = 0; l < cnti; ++l) {
+            const float di = rl_f(dist[ci], (int)l);
+            const uint32_t i = basei + l;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+              const uint32_t me = 64u * c + lane;
+              rank[c] += (di < dist[c]) || (!(dist[c] < di) && !(di < dist[c]) && i < me);
+            }
+          }
         }
         __syncthreads();
-        if (lane < dg && rank < p.m0) row[rank] = rid;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+          if (64u * c + lane < dg && rank[c] < p.m0) row[rank[c]] = rid[c];
         dg = p.m0;
       }
       if (lane == 0) *((volatile uint32_t*)&p.ell_deg[nid]) = dg;
@@ -197,7 +222,7 @@ extern "C" isl_status isl_index_build(const isl_leann_config* cfg_in, const floa
   ISL_TRY(isl_leann_config_validate(&cfg));
   if (n == 0) return isl_index_new(&cfg, out);  // build(&[]) -> Ok(()), leann.rs:565-567
   if (d == 0) return fail(ISL_ERR_EMPTY_COLLECTION, "Empty vector collection");
-  if (cfg.m0 > 63) return fail(ISL_ERR_UNSUPPORTED, "the device builder keeps rows of up to 64 ids: m0 <= 63");
+  if (cfg.m0 > 128) return fail(ISL_ERR_UNSUPPORTED, "the device builder keeps rows of up to 129 ids: m0 <= 128");
   if (cfg.ef_construction > 512) return fail(ISL_ERR_UNSUPPORTED, "ef_construction <= 512 on the device");
   if (n >= 0x7FFFFFF0ull) return fail(ISL_ERR_UNSUPPORTED, "num_nodes exceeds the device id range");
   if (batch == 0) batch = 1;
@@ -215,7 +240,7 @@ extern "C" isl_status isl_index_build(const isl_leann_config* cfg_in, const floa
   g->device = device;
   g->has_dimension = true;
   g->dimension = d;
-  g->max_degree = W;
+  g->max_degree = m0;  // what a construction search can meet: a row is back at <= m0 ids before the next search
   isl_status st = isl_set_embeddings(g, vectors, n, d, ISL_DTYPE_F32, mem);
   if (st != ISL_OK) return bail(st);
   std::vector<void*> tmp;

@@ -1,0 +1,28 @@
+// leann_search_fast<S = 8> for every metric, row type and row width (see search_kernels.hip.h).
+#include "search_kernels.hip.h"
+
+namespace {
+template <typename ROWT, bool WIDE>
+void launch_t(int metric, uint32_t grid, size_t lds, hipStream_t st, const SearchParams& p) {
+  switch (metric) {
+    case ISL_METRIC_COSINE: launch_one(leann_search_fast<8, ISL_METRIC_COSINE, ROWT, WIDE>, grid, lds, st, p); break;
+    case ISL_METRIC_EUCLIDEAN: launch_one(leann_search_fast<8, ISL_METRIC_EUCLIDEAN, ROWT, WIDE>, grid, lds, st, p); break;
+    case ISL_METRIC_DOT: launch_one(leann_search_fast<8, ISL_METRIC_DOT, ROWT, WIDE>, grid, lds, st, p); break;
+    default: launch_one(leann_search_fast<8, ISL_METRIC_MANHATTAN, ROWT, WIDE>, grid, lds, st, p); break;
+  }
+}
+}  // namespace
+
+// wide = the index has adjacency rows of 65..128 ids (its own instantiation: the common case keeps
+// its register budget)
+void isl_launch::launch_fast_s8(int metric, bool wide, bool bf16, uint32_t grid, size_t lds, hipStream_t st,
+                                 const void* params) {
+  const SearchParams& p = *static_cast<const SearchParams*>(params);
+  if (bf16) {
+    if (wide) launch_t<uint16_t, true>(metric, grid, lds, st, p);
+    else launch_t<uint16_t, false>(metric, grid, lds, st, p);
+  } else {
+    if (wide) launch_t<float, true>(metric, grid, lds, st, p);
+    else launch_t<float, false>(metric, grid, lds, st, p);
+  }
+}

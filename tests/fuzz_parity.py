@@ -38,7 +38,7 @@ def one_case(rng, case):
     elif quant < 0.4:  # duplicated rows
         vec[n // 2:] = vec[:n - n // 2]
     vec = vec.astype(np.float32)
-    deg = int(rng.choice([4, 12, 30, 60, 64]))
+    deg = int(rng.choice([4, 12, 30, 60, 64, 65, 96, 128, 140]))  # rows past 64 ids: two ids per lane; past 128: heap-exact kernel
     if rng.random() < 0.5 and n >= 64:
         off, nb = knn_graph(vec, min(deg, n - 1), seed)
     else:
@@ -123,8 +123,8 @@ def build_case(rng, case):
     if rng.random() < 0.25:
         v = (np.round(v * 2) / 2).astype(np.float32)
         v[np.abs(v).sum(1) == 0, 0] = 1.0
-    m0 = int(rng.choice([4, 12, 32, 60]))
-    cfg = ia.LeannConfig(m=max(2, m0 // 2), m0=m0, ef_construction=int(rng.choice([m0, 2 * m0, 128])),
+    m0 = int(rng.choice([4, 12, 32, 60, 64, 96, 128]))  # rows past 64 ids included (accurate(): 96)
+    cfg = ia.LeannConfig(m=max(2, m0 // 2), m0=m0, ef_construction=int(rng.choice([m0, 2 * m0, max(128, m0)])),
                          metric=ia.DistanceMetric(int(rng.integers(0, 4))),
                          hub_percentile=float(rng.choice([0.02, 0.1, 0.5])),
                          high_degree_pruning=bool(rng.random() < 0.8))

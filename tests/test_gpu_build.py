@@ -110,5 +110,28 @@ def test_build_edge_cases():
     one = ia.LeannIndex.build(np.ones((1, 8), np.float32))
     assert len(one) == 1 and one.entry_point == 0 and one.search(np.ones(8, np.float32), 3)[0][0] == 0
     with pytest.raises(ia.CoreError) as ex:
-        ia.LeannIndex.build(np.ones((4, 8), np.float32), ia.LeannConfig.accurate())  # m0 = 96
+        ia.LeannIndex.build(np.ones((4, 8), np.float32), ia.LeannConfig(m=64, m0=129, ef_construction=200))
     assert ex.value.kind == "Unsupported"
+
+
+@pytest.mark.parametrize("m,m0,efc", [(48, 96, 400), (64, 128, 256), (33, 65, 100)])
+def test_accurate_preset_build_is_the_reference_graph(orc, m, m0, efc):
+    """LeannConfig::accurate() (m = 48, m0 = 96, ef_construction = 400; leann.rs:419-429) and the
+    edges of the wide-row range: rows outgrow 64 ids, the distance re-sort of prune_neighbors_temp
+    (leann.rs:634-658) runs over up to 129 entries.  Byte-equal to the oracle's sequential build."""
+    n, d = 420, 12
+    v = uniform_vectors(n, d, 31 + m0)
+    cfg = ia.LeannConfig.accurate()
+    cfg.m, cfg.m0, cfg.ef_construction = m, m0, efc
+    levels = random_levels(n, m, 5)
+    want, csr = reference_bytes(orc, v, cfg, levels)
+    idx = ia.LeannIndex.build(v, cfg, levels=levels, batch=1)
+    assert idx.to_bytes() == want
+    assert max(len(idx.get_neighbors(i)) for i in range(n)) > 64  # the case is what it claims to be
+    q = uniform_vectors(10, d, 77)
+    ids, dist, cnt = idx.search_batch(q, 10, cfg.ef_search)
+    assert idx.last_stats()["exact_path"] == 0
+    for i in range(10):
+        r = orc.leann_search(csr, v, q[i], 10, cfg.ef_search)
+        assert ids[i, :cnt[i]].tolist() == r.ids.tolist()
+        assert dist[i, :cnt[i]].view(np.uint32).tolist() == r.dist.view(np.uint32).tolist()

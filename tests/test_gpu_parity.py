@@ -192,12 +192,48 @@ def test_ties_duplicates_and_dup_rows_take_exact_path(orc):
         assert st["exact_path"] + st["replayed"] > 0
 
 
-def test_long_rows_use_exact_kernel(orc):  # LeannConfig::accurate(): m0 = 96 > 64 lanes
-    n, d = 300, 16
-    v = uniform_vectors(n, d, 60)
-    off, nb = random_csr(n, 96, 61)
+@pytest.mark.parametrize("deg,ef,metric", [(96, 128, 0), (128, 64, 1), (65, 16, 2), (100, 300, 3), (127, 600, 0)])
+def test_long_rows_on_the_fast_path(orc, deg, ef, metric):
+    """LeannConfig::accurate() has m0 = 96 (leann.rs:419-429): adjacency rows of up to 128 ids are
+    answered by the wave-per-query kernel (two ids per lane, neighbours evaluated 64 at a time in
+    CSR order), not by the lane-0 heap emulation."""
+    n, d = 1500, 24
+    v = uniform_vectors(n, d, 60 + deg)
+    off, nb = random_csr(n, deg, 61)
     csr = orc.Csr(off, nb, entry_point=0)
-    idx = make_index(csr, v, ia.LeannConfig.accurate())
+    cfg = ia.LeannConfig.accurate()
+    cfg.metric = METRICS[metric]
+    idx = make_index(csr, v, cfg)
+    q = uniform_vectors(24, d, 62)
+    st, tot = assert_same_search(orc, idx, csr, v, q, 10, ef, metric=metric)
+    assert st["exact_path"] == 0 or ef > 512  # distinct distances: nothing for the heap-exact kernel
+    for f in tot:
+        assert st[f] == tot[f], f
+
+
+def test_long_rows_with_pruning_and_ties(orc):
+    """Rows of 65..128 ids with prune_ratio > 0 (the keep prefix is computed over the whole row,
+    leann.rs:991-1016) and quantised vectors (equal distances everywhere: tie replay / exact kernel)."""
+    n, d = 900, 8
+    rng = np.random.default_rng(5)
+    v = rng.integers(-2, 3, (n, d)).astype(np.float32)
+    v[np.abs(v).sum(1) == 0, 0] = 1
+    off, nb = random_csr(n, 110, 7)
+    csr = orc.Csr(off, nb, entry_point=3)
+    for strategy in (ia.PruningStrategy.Global, ia.PruningStrategy.Local):
+        cfg = ia.LeannConfig(m=48, m0=110, ef_construction=400, prune_ratio=0.4, pruning_strategy=strategy,
+                             metric=ia.DistanceMetric.Euclidean)
+        idx = make_index(csr, v, cfg)
+        q = rng.integers(-2, 3, (16, d)).astype(np.float32)
+        assert_same_search(orc, idx, csr, v, q, 7, 40, metric=1, prune_ratio=0.4, strategy=int(strategy))
+
+
+def test_rows_beyond_128_ids_use_the_exact_kernel(orc):
+    n, d = 400, 16
+    v = uniform_vectors(n, d, 60)
+    off, nb = random_csr(n, 140, 61)
+    csr = orc.Csr(off, nb, entry_point=0)
+    idx = make_index(csr, v, ia.LeannConfig(m=48, m0=140, ef_construction=400))
     st, _ = assert_same_search(orc, idx, csr, v, uniform_vectors(8, d, 62), 10, 128)
     assert st["exact_path"] == 8
 
