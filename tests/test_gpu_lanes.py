@@ -115,10 +115,10 @@ def test_last_stats_is_per_thread(orc):
 
 
 def test_exact_pool_shared_by_concurrent_launches(orc):
-    """Rows longer than 64 ids send every query to the heap-exact kernel; eight such calls in
+    """Rows longer than 128 ids send every query to the heap-exact kernel; eight such calls in
     flight share the one scratch pool (32 slots) and still answer like the oracle."""
     rng = np.random.default_rng(77)
-    n, d, deg = 900, 48, 90
+    n, d, deg = 900, 48, 150
     v = clustered_vectors(n, d, 78)
     nb = np.stack([rng.permutation(n)[:deg] for _ in range(n)]).astype(np.uint64)
     off = (np.arange(n + 1) * deg).astype(np.uint64)
