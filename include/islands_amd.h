@@ -409,6 +409,12 @@ isl_status isl_encoder_embed(isl_encoder* enc, const int64_t* input_ids, const i
 isl_status isl_set_recompute_provider(isl_index* idx, isl_encoder* enc, const uint16_t* tokens,
                                       const uint16_t* lengths, uint64_t n, uint64_t L,
                                       int32_t normalize, int32_t keep_rows, int32_t mem);
+/* The recompute provider does not store embeddings (leann.rs:366-371); what it keeps on the device
+ * is the token table and a bounded row cache: a slab of `rows` embedding rows (default 2^20, or
+ * every node of a smaller index; at least 256) plus 4 bytes of slot map per node.  Slots are handed
+ * out round-robin, the oldest rows make room.  isl_index_recompute_cache_bytes = what that costs. */
+isl_status isl_index_set_recompute_cache_rows(isl_index* idx, uint64_t rows);
+uint64_t isl_index_recompute_cache_bytes(const isl_index* idx);
 
 /* ---- embedding/candle_provider.rs:434-488: masked mean-pool + optional L2 normalise ----
  * hidden [B][L][H] f32, mask [B][L] (0/1 as f32), out [B][H].  The BERT forward that

@@ -414,18 +414,31 @@ class LeannIndex:
         _check(_ffi.lib().isl_index_upload(self._h, device))
         return self
 
-    def set_recompute_provider(self, embedder: "CandleEmbedder", tokens, lengths=None,
-                               keep_rows: bool = False) -> "LeannIndex":
+    def set_recompute_provider(self, embedder: "CandleEmbedder", tokens=None, lengths=None,
+                               keep_rows: bool = False, cache_rows: int | None = None,
+                               device_ptr: int | None = None, n: int | None = None,
+                               L: int | None = None) -> "LeannIndex":
         """EmbeddingProvider backed by the encoder (recompute mode, leann.rs:82-99): `tokens`
-        [n, L] uint16 holds node i's tokenised text in row i, `lengths[i]` slots of it used."""
-        t = np.ascontiguousarray(tokens, dtype=np.uint16)
-        ln = None if lengths is None else np.ascontiguousarray(lengths, dtype=np.uint16)
-        n, L = t.shape
-        _check(_ffi.lib().isl_set_recompute_provider(
-            self._h, embedder._h, _ptr(t), None if ln is None else _ptr(ln), n, L,
-            int(embedder.normalize), int(keep_rows), MEM_HOST))
+        [n, L] uint16 holds node i's tokenised text in row i, `lengths[i]` slots of it used (or a
+        device pointer to such a table).  cache_rows = rows of the bounded embedding cache."""
+        if device_ptr is not None:
+            _check(_ffi.lib().isl_set_recompute_provider(
+                self._h, embedder._h, C.c_void_p(device_ptr), None, n, L, int(embedder.normalize),
+                int(keep_rows), MEM_DEVICE))
+        else:
+            t = np.ascontiguousarray(tokens, dtype=np.uint16)
+            ln = None if lengths is None else np.ascontiguousarray(lengths, dtype=np.uint16)
+            n, L = t.shape
+            _check(_ffi.lib().isl_set_recompute_provider(
+                self._h, embedder._h, _ptr(t), None if ln is None else _ptr(ln), n, L,
+                int(embedder.normalize), int(keep_rows), MEM_HOST))
+        if cache_rows is not None:
+            _check(_ffi.lib().isl_index_set_recompute_cache_rows(self._h, cache_rows))
         self._embedder = embedder  # borrowed by the library: keep it alive
         return self
+
+    def recompute_cache_bytes(self) -> int:
+        return int(_ffi.lib().isl_index_recompute_cache_bytes(self._h))
 
     def set_embeddings(self, rows, device_ptr: int | None = None, n: int | None = None,
                        d: int | None = None) -> "LeannIndex":

@@ -142,6 +142,8 @@ SIGNATURES = {
                                 C.c_void_p, i32, C.c_void_p]),
     "isl_set_recompute_provider": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u64, u64,
                                          i32, i32, i32]),
+    "isl_index_set_recompute_cache_rows": (i32, [C.c_void_p, u64]),
+    "isl_index_recompute_cache_bytes": (u64, [C.c_void_p]),
     "isl_mean_pool_normalize": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, i32, C.c_void_p, i32,
                                       i32, C.c_void_p]),
     "isl_hnsw_from_layers": (i32, [u64, u64, u64, i32, u64, u64, u64, C.c_void_p, C.c_void_p,

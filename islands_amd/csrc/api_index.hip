@@ -274,7 +274,8 @@ void isl_index_free(isl_index* idx) {
     if (idx->d_emb16) (void)hipFree(idx->d_emb16);
     if (idx->d_tokens) (void)hipFree(idx->d_tokens);
     if (idx->d_lens) (void)hipFree(idx->d_lens);
-    if (idx->d_present) (void)hipFree(idx->d_present);
+    if (idx->d_slot_of) (void)hipFree(idx->d_slot_of);
+    if (idx->d_owner) (void)hipFree(idx->d_owner);
     if (idx->d_off) (void)hipFree(idx->d_off);
     if (idx->d_adj) (void)hipFree(idx->d_adj);
     if (idx->d_emb) (void)hipFree(idx->d_emb);
@@ -780,6 +781,44 @@ isl_status isl_set_embeddings(isl_index* idx, const void* rows, uint64_t n, uint
   return ISL_OK;
 }
 
+// (re)allocates the recompute provider's row cache: slab, per-slot norms, slot map, owners
+static isl_status alloc_recompute_cache(isl_index* idx, uint64_t rows) {
+  void* olds[] = {idx->d_emb, idx->d_norm2, idx->d_slot_of, idx->d_owner};
+  for (void* p : olds)
+    if (p) (void)hipFree(p);
+  idx->d_emb = nullptr; idx->d_norm2 = nullptr; idx->d_slot_of = nullptr; idx->d_owner = nullptr;
+  idx->slab_rows = 0;
+  idx->slab_head = 0;
+  const uint64_t stride = idx->emb_stride, n = idx->nvec;
+  ISL_HIP(hipMalloc(&idx->d_emb, (size_t)(rows * stride + 256) * sizeof(float)));
+  ISL_HIP(hipMemset(idx->d_emb, 0, (size_t)(rows * stride + 256) * sizeof(float)));
+  ISL_HIP(hipMalloc(&idx->d_norm2, (size_t)rows * 4));
+  ISL_HIP(hipMemset(idx->d_norm2, 0, (size_t)rows * 4));
+  ISL_HIP(hipMalloc(&idx->d_slot_of, (size_t)(n + 1) * 4));
+  ISL_HIP(hipMemset(idx->d_slot_of, 0xFF, (size_t)(n + 1) * 4));
+  ISL_HIP(hipMalloc(&idx->d_owner, (size_t)rows * 4));
+  ISL_HIP(hipMemset(idx->d_owner, 0xFF, (size_t)rows * 4));
+  idx->slab_rows = rows;
+  return ISL_OK;
+}
+
+isl_status isl_index_set_recompute_cache_rows(isl_index* idx, uint64_t rows) {
+  if (!idx) return fail(ISL_ERR_INVALID_ARGUMENT, "index is NULL");
+  if (!idx->recompute) return fail(ISL_ERR_INVALID_ARGUMENT, "the index has no recompute provider");
+  ISL_TRY(use_device(idx->device));
+  std::lock_guard<std::mutex> lock(idx->mu);
+  if (any_lane_busy(idx))
+    return fail(ISL_ERR_SEARCH, "Search error: the row cache cannot be resized while searches are in flight");
+  // a hop of one query needs up to 128 rows at once (plus the entry point): that is the floor
+  rows = std::min<uint64_t>(idx->nvec, std::max<uint64_t>(rows, 256));
+  return alloc_recompute_cache(idx, rows);
+}
+
+uint64_t isl_index_recompute_cache_bytes(const isl_index* idx) {
+  if (!idx || !idx->recompute) return 0;
+  return (idx->slab_rows * idx->emb_stride + 256) * 4 + idx->slab_rows * 8 + (idx->nvec + 1) * 4;
+}
+
 // EmbeddingProvider backed by the encoder (recompute mode), see islands_amd.h.
 isl_status isl_set_recompute_provider(isl_index* idx, isl_encoder* enc, const uint16_t* tokens,
                                       const uint16_t* lengths, uint64_t n, uint64_t L,
@@ -800,22 +839,21 @@ isl_status isl_set_recompute_provider(isl_index* idx, isl_encoder* enc, const ui
   const uint64_t d = enc->cfg.hidden, stride = (d + 3) / 4 * 4;
   // (d_emb16 too: bf16 rows of an earlier in-memory provider would otherwise stay the table the
   // searches read)
-  void* olds[] = {idx->d_emb, idx->d_emb16, idx->d_norm2, idx->d_tokens, idx->d_lens, idx->d_present};
+  void* olds[] = {idx->d_emb, idx->d_emb16, idx->d_norm2, idx->d_tokens, idx->d_lens, idx->d_slot_of, idx->d_owner};
   for (void* p : olds)
     if (p) (void)hipFree(p);
   idx->d_emb = nullptr; idx->d_emb16 = nullptr; idx->d_norm2 = nullptr; idx->d_tokens = nullptr;
-  idx->d_lens = nullptr; idx->d_present = nullptr;
+  idx->d_lens = nullptr; idx->d_slot_of = nullptr; idx->d_owner = nullptr;
   free_exact_pool(idx->pool);
   idx->recompute = false;
-  // the row table is addressed by node id like the in-memory provider's; rows are valid only
-  // where d_present says so (288 GB of HBM make a dense table the simplest cache)
-  ISL_HIP(hipMalloc(&idx->d_emb, (size_t)(n * stride + 256) * sizeof(float)));
-  ISL_HIP(hipMemset(idx->d_emb, 0, (size_t)(n * stride + 256) * sizeof(float)));
-  ISL_HIP(hipMalloc(&idx->d_norm2, (size_t)n * 4));
-  ISL_HIP(hipMemset(idx->d_norm2, 0, (size_t)n * 4));
-  idx->present_words = (n + 31) / 32 + 1;
-  ISL_HIP(hipMalloc(&idx->d_present, idx->present_words * 4));
-  ISL_HIP(hipMemset(idx->d_present, 0, idx->present_words * 4));
+  // Recompute mode does not store embeddings (leann.rs:366-371): what is resident is the token
+  // table plus a BOUNDED row cache -- a slab of slab_rows rows, 4 bytes of slot map per node.  The
+  // default slab (2^20 rows, or every node of a smaller index) holds what a batch of a thousand
+  // queries visits; isl_index_set_recompute_cache_rows changes it.
+  idx->nvec = n;
+  idx->emb_d = d;
+  idx->emb_stride = stride;
+  ISL_TRY(alloc_recompute_cache(idx, std::min<uint64_t>(n, 1ull << 20)));
   hipMemcpyKind kind = mem == ISL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   ISL_HIP(hipMalloc(&idx->d_tokens, (size_t)n * L * 2));
   ISL_HIP(hipMemcpy(idx->d_tokens, tokens, (size_t)n * L * 2, kind));

@@ -105,6 +105,20 @@ struct SearchWorkspace {
   uint32_t* uniq = nullptr;
   uint32_t* uniq_count = nullptr;
   uint64_t miss_cap = 0;
+  // ... and, for the searches that park and resume (fast kernel over the recompute provider): the
+  // parked state of every query, its flag, the list of queries a round runs
+  uint32_t* qstate = nullptr;
+  uint64_t qstate_words = 0;     // allocated, in words
+  uint32_t* qflag = nullptr;     // [qlist_cap]
+  uint32_t* qlist = nullptr;     // [qlist_cap] device
+  uint32_t* h_qlist = nullptr;   // [qlist_cap] pinned
+  uint32_t* uslots = nullptr;    // [miss_cap] slab slots of the round's unique misses
+  uint64_t qlist_cap = 0;
+  // the round search_sync is about to enqueue (recompute provider): 0 = an ordinary launch over
+  // all queries; otherwise the RESUME kernel over `round_active` queries, listed in qlist unless
+  // it is the first round
+  uint32_t round_active = 0;
+  bool round_listed = false;
   // two-level search: per-query PQ distance tables [nq][m * K]
   float* tl_tables = nullptr;
   uint64_t tl_tables_cap = 0;
@@ -176,15 +190,20 @@ struct isl_index {
   uint32_t ell_w = 0;
   bool ell_owned = false;         // the padded copy made at the first search (freed with the index)
 
-  // recompute provider (EmbeddingProvider backed by the encoder, leann.rs:82-99): rows of d_emb
-  // exist only where d_present has a bit; the search reports the rows it misses and the
-  // provider encodes them from the resident token table
+  // recompute provider (EmbeddingProvider backed by the encoder, leann.rs:82-99): embeddings are
+  // not stored (leann.rs:366-371); the search reports the rows it misses and the provider encodes
+  // them from the resident token table into a bounded row cache
   struct isl_encoder* enc = nullptr;   // borrowed
   uint16_t* d_tokens = nullptr;        // [nvec][tok_L]
   uint16_t* d_lens = nullptr;          // [nvec] or NULL
   uint32_t tok_L = 0;
-  uint32_t* d_present = nullptr;       // bitmap over node ids
-  uint64_t present_words = 0;
+  // the rows live in a bounded slab (d_emb / d_norm2 indexed by SLOT): slot_of[id] = the node's
+  // slot or 0xFFFFFFFF, owner[slot] = the node in it; slots are handed out round-robin, so the
+  // oldest rows make room once the slab is full
+  uint32_t* d_slot_of = nullptr;       // [nvec]
+  uint32_t* d_owner = nullptr;         // [slab_rows]
+  uint64_t slab_rows = 0;
+  mutable uint64_t slab_head = 0;      // next slot to hand out (under recompute_mu)
   bool recompute = false, keep_rows = false;
   int32_t enc_normalize = 1;
 

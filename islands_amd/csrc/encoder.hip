@@ -473,8 +473,9 @@ isl_status check_ids_flag(isl_encoder* e, hipStream_t st) {
 namespace isl {
 isl_status encoder_embed_nodes(isl_encoder* e, const uint16_t* d_tokens, const uint16_t* d_lens,
                                uint32_t L, const uint32_t* d_node_ids, uint64_t n, int normalize,
-                               float* d_rows, uint64_t stride, hipStream_t st) {
+                               float* d_rows, uint64_t stride, hipStream_t st, const uint32_t* d_out_rows) {
   if (n == 0) return ISL_OK;
+  if (!d_out_rows) d_out_rows = d_node_ids;
   if (L == 0 || L > e->cfg.max_position)
     return isl::fail(ISL_ERR_EMBEDDING, "Embedding error: token rows of %u slots do not fit max_position %u",
                      L, e->cfg.max_position);
@@ -487,7 +488,7 @@ isl_status encoder_embed_nodes(isl_encoder* e, const uint16_t* d_tokens, const u
                        d_lens, L, d_node_ids + o, B, e->d_ids, e->d_mask);
     ISL_TRY(compute_forward(e, false, B, L, st));
     hipLaunchKernelGGL(pool_kernel, dim3((uint32_t)B), dim3(64), 0, st, e->x, e->d_mask, L,
-                       (uint32_t)e->cfg.hidden, normalize, d_rows, d_node_ids + o, stride);
+                       (uint32_t)e->cfg.hidden, normalize, d_rows, d_out_rows + o, stride);
     ISL_HIP(hipGetLastError());
     ISL_TRY(check_ids_flag(e, st));
   }

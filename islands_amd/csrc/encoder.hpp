@@ -35,7 +35,9 @@ namespace isl {
 // = node i, `L` slots per node, d_lens[i] of them used; NULL = all) and writes embedding b to
 // d_rows + d_node_ids[b] * stride.  Sequences are padded to L: masked keys contribute exact
 // zeros, so the result does not depend on the padded length.
+// d_out_rows (device, may be NULL = the node ids): embedding b goes to d_rows + d_out_rows[b] * stride.
 isl_status encoder_embed_nodes(isl_encoder* e, const uint16_t* d_tokens, const uint16_t* d_lens,
                                uint32_t L, const uint32_t* d_node_ids, uint64_t n, int normalize,
-                               float* d_rows, uint64_t stride, hipStream_t st);
+                               float* d_rows, uint64_t stride, hipStream_t st,
+                               const uint32_t* d_out_rows = nullptr);
 }  // namespace isl

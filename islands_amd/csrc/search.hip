@@ -377,8 +377,13 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   const bool use_fast = cg.use_fast;
   const FastGeom& fg = cg.fg;
   const uint32_t slots = cg.slots, plog_cap = cg.plog_cap;
-  // per-slot state is indexed by blockIdx.x < min(nq, slots)
-  if (!warm) ISL_TRY(prepare_workspace(ws, (uint32_t)nq, (uint32_t)std::min<uint64_t>(nq, slots), plog_cap));
+  // searches over the recompute provider park and resume on the fast kernel (f32 rows; the
+  // two-level and heap-exact kernels re-run a blocked query from its start instead)
+  const bool resume = !warm && ws.round_active != 0 && use_fast && !tl;
+  // per-slot state is indexed by blockIdx.x < min(nq, slots) -- by the query when it can come back on
+  // another wave
+  if (!warm)
+    ISL_TRY(prepare_workspace(ws, (uint32_t)nq, (uint32_t)(idx->recompute ? nq : std::min<uint64_t>(nq, slots)), plog_cap));
   if (!idx->pool.slots || ((use_fast || (tl && idx->max_degree <= 128)) && !idx->d_ell && idx->d_off && idx->num_nodes)) {
     // not prepared (isl_index_prepare / isl_index_upload do this ahead of time)
     std::lock_guard<std::mutex> lock(idx->mu);
@@ -442,7 +447,13 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   p.ulist_cap = idx->pool.ulist_cap;
   p.pool_locks = idx->pool.locks;
   p.pool_slots = idx->pool.slots;
-  p.present = idx->recompute ? idx->d_present : nullptr;
+  p.slot_of = idx->recompute ? idx->d_slot_of : nullptr;
+  if (resume) {
+    p.qstate = ws.qstate;
+    p.qstate_words = isl_launch::fast_state_words(ef <= 64 ? 1 : ef <= 128 ? 2 : ef <= 256 ? 4 : 8, fg.hbits);
+    p.qflag = ws.qflag;
+    p.qlist = ws.round_listed ? ws.qlist : nullptr;
+  }
   p.miss = ws.miss;
   p.miss_cap = (uint32_t)std::min<uint64_t>(ws.miss_cap, 0xFFFFFFFFull);
   p.layer_off = idx->d_layer_off;
@@ -492,18 +503,20 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   }
   if (tl) {
   } else if (use_fast) {
-    uint32_t grid = (uint32_t)std::min<uint64_t>(nq_grid, slots);
+    if (resume) p.nq = ws.round_active;  // the fast kernel runs this round's queries; nothing else reads nq
+    uint32_t grid = (uint32_t)std::min<uint64_t>(resume ? ws.round_active : nq_grid, slots);
     int S = ef <= 64 ? 1 : ef <= 128 ? 2 : ef <= 256 ? 4 : 8;
     const int metric = (int)idx->cfg.metric;
     const bool wide = idx->max_degree > 64;
     const bool bf16 = p.emb_bf16 != 0;
     switch (S) {
-      case 1: isl_launch::launch_fast_s1(metric, wide, bf16, grid, fg.lds, st, &p); break;
-      case 2: isl_launch::launch_fast_s2(metric, wide, bf16, grid, fg.lds, st, &p); break;
-      case 4: isl_launch::launch_fast_s4(metric, wide, bf16, grid, fg.lds, st, &p); break;
-      default: isl_launch::launch_fast_s8(metric, wide, bf16, grid, fg.lds, st, &p); break;
+      case 1: isl_launch::launch_fast_s1(metric, wide, bf16, resume, grid, fg.lds, st, &p); break;
+      case 2: isl_launch::launch_fast_s2(metric, wide, bf16, resume, grid, fg.lds, st, &p); break;
+      case 4: isl_launch::launch_fast_s4(metric, wide, bf16, resume, grid, fg.lds, st, &p); break;
+      default: isl_launch::launch_fast_s8(metric, wide, bf16, resume, grid, fg.lds, st, &p); break;
     }
     ISL_HIP(hipGetLastError());
+    p.nq = (uint32_t)nq;
   } else if (!warm) {
     // every query goes to the exact kernel: redo = [0, nq)
     std::vector<uint32_t> all(nq);
@@ -631,15 +644,32 @@ isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws, uint32_
 }
 
 // ---- recompute provider (EmbeddingProvider backed by the encoder, leann.rs:82-99) ----
-// marks the missed ids present and lists each of them once
+// lists each missed id once: the first reporter of an id claims its slot-map entry
 __global__ void dedupe_misses_kernel(const uint32_t* __restrict__ miss, uint32_t n,
-                                     uint32_t* __restrict__ present, uint32_t* __restrict__ uniq,
+                                     uint32_t* __restrict__ slot_of, uint32_t* __restrict__ uniq,
                                      uint32_t* __restrict__ uniq_count) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t id = miss[i], bit = 1u << (id & 31);
-  const uint32_t old = atomicOr(&present[id >> 5], bit);
-  if (!(old & bit)) uniq[atomicAdd(uniq_count, 1u)] = id;
+  const uint32_t id = miss[i];
+  if (atomicCAS(&slot_of[id], kNoSlot, kSlotClaim) == kNoSlot) uniq[atomicAdd(uniq_count, 1u)] = id;
+}
+
+// Hands the round's unique misses their slab slots, round-robin from `head`: the node that held a
+// slot before loses its row (its map entry goes back to "absent").  Misses beyond `take` (more
+// than the slab can hold at once) are un-claimed and reported again next round.
+__global__ void assign_slots_kernel(const uint32_t* __restrict__ uniq, uint32_t n, uint32_t take, uint64_t head,
+                                    uint64_t slab_rows, uint32_t* __restrict__ slot_of,
+                                    uint32_t* __restrict__ owner, uint32_t* __restrict__ uslots) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t id = uniq[i];
+  if (i >= take) { slot_of[id] = kNoSlot; return; }
+  const uint32_t s = (uint32_t)((head + i) % slab_rows);
+  const uint32_t old = owner[s];
+  if (old != kNoSlot) slot_of[old] = kNoSlot;  // (never one of this round's ids: those were absent)
+  owner[s] = id;
+  slot_of[id] = s;
+  uslots[i] = s;
 }
 
 // norm2[id] = sum_j row[id][j]^2 in the reference's order for the freshly encoded rows
@@ -657,19 +687,33 @@ __global__ __launch_bounds__(64) void row_norm2_list_kernel(const float* __restr
   }
 }
 
-isl_status prepare_recompute(isl::SearchWorkspace& ws, uint64_t nq) {
-  const uint64_t cap = std::min<uint64_t>(nq * 64 + 64, 0xFFFFFFF0ull);
+isl_status prepare_recompute(isl::SearchWorkspace& ws, uint64_t nq, uint64_t state_words_per_query) {
+  const uint64_t cap = std::min<uint64_t>(nq * 128 + 64, 0xFFFFFFF0ull);  // a hop keeps up to 128 rows
   if (ws.miss_cap < cap) {
-    void* ptrs[] = {ws.miss, ws.uniq, ws.uniq_count};
+    void* ptrs[] = {ws.miss, ws.uniq, ws.uniq_count, ws.uslots};
     for (void* q : ptrs)
       if (q) (void)hipFree(q);
-    ws.miss = ws.uniq = ws.uniq_count = nullptr;
+    ws.miss = ws.uniq = ws.uniq_count = ws.uslots = nullptr;
     ws.miss_cap = 0;
     ISL_TRY(lane_malloc(ws, ws.miss, cap * 4));
     ISL_TRY(lane_malloc(ws, ws.uniq, cap * 4));
+    ISL_TRY(lane_malloc(ws, ws.uslots, cap * 4));
     ISL_TRY(lane_malloc(ws, ws.uniq_count, 4));
     ws.miss_cap = cap;
   }
+  if (ws.qlist_cap < nq) {
+    if (ws.qflag) (void)hipFree(ws.qflag);
+    if (ws.qlist) (void)hipFree(ws.qlist);
+    if (ws.h_qlist) (void)hipHostFree(ws.h_qlist);
+    ws.qflag = ws.qlist = ws.h_qlist = nullptr;
+    ws.qlist_cap = 0;
+    const uint64_t c = nq < 1024 ? 1024 : nq;
+    ISL_TRY(lane_malloc(ws, ws.qflag, c * 4));
+    ISL_TRY(lane_malloc(ws, ws.qlist, c * 4));
+    ISL_TRY(lane_host_malloc(ws, ws.h_qlist, c * 4));
+    ws.qlist_cap = c;
+  }
+  ISL_TRY(ensure(ws, ws.qstate, ws.qstate_words, std::max<uint64_t>(nq, 1) * state_words_per_query));
   return ISL_OK;
 }
 
@@ -695,17 +739,33 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
       return st;
     }
   }
-  // the rounds rewrite the provider's row table and presence bitmap: one recompute search at a time
+  // the rounds rewrite the provider's row cache: one recompute search at a time
   std::lock_guard<std::mutex> rlock(idx->recompute_mu);
-  ISL_TRY(prepare_recompute(ws, nq));
+  CallGeometry cg0;
+  ISL_TRY(call_geometry(idx, d, k, ef, tl, cg0));
+  const int S0 = cg0.ef <= 64 ? 1 : cg0.ef <= 128 ? 2 : cg0.ef <= 256 ? 4 : 8;
+  const bool resumable = cg0.use_fast && !tl;
+  ISL_TRY(prepare_recompute(ws, nq, resumable ? isl_launch::fast_state_words(S0, cg0.fg.hbits) : 1));
   ISL_TRY(ensure_lane_stream(ws));
-  if (!idx->keep_rows)
-    ISL_HIP(hipMemsetAsync(idx->d_present, 0, idx->present_words * 4, mode == StreamMode::USER ? user_stream : ws.stream));
+  hipStream_t st = mode == StreamMode::USER ? user_stream : ws.stream;
+  if (!idx->keep_rows) {  // every call starts from an empty cache: each node is encoded once per call
+    ISL_HIP(hipMemsetAsync(idx->d_slot_of, 0xFF, (idx->nvec + 1) * 4, st));
+    ISL_HIP(hipMemsetAsync(idx->d_owner, 0xFF, idx->slab_rows * 4, st));
+    idx->slab_head = 0;
+  }
+  ISL_HIP(hipMemsetAsync(ws.qflag, 0, nq * 4, st));
   uint64_t encoded = 0, rounds = 0;
   double kernel_ms = 0.0;
+  uint32_t active = (uint32_t)nq;
+  bool listed = false;
+  struct RoundReset {  // the lane goes back with its round fields cleared whatever happens below
+    isl::SearchWorkspace& w;
+    ~RoundReset() { w.round_active = 0; w.round_listed = false; }
+  } reset{ws};
   for (;;) {
+    ws.round_active = resumable ? active : 0u;
+    ws.round_listed = listed;
     ISL_TRY(search_enqueue(idx, ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, user_stream, mode, tl));
-    hipStream_t st = mode == StreamMode::USER ? user_stream : ws.stream;
     uint32_t misses = 0;
     bool window_short = false;
     const isl_status fst = search_finish(idx, ws, &misses, tl ? &window_short : nullptr);
@@ -714,20 +774,37 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
     kernel_ms += ws.stats.kernel_ms;
     rounds += 1;
     if (!misses) break;
+    if (rounds > 200000)
+      return isl::fail(ISL_ERR_SEARCH, "Search error: the recompute provider's row cache (%llu rows) is too small "
+                       "for this batch", (unsigned long long)idx->slab_rows);
+    if (resumable) {  // next round: the queries that are waiting for rows
+      uint32_t na = 0;
+      for (uint64_t i = 0; i < nq; ++i)
+        if (ws.h_status[i] == QS_BLOCKED) ws.h_qlist[na++] = (uint32_t)i;
+      active = na;
+      listed = true;
+      hipLaunchKernelGGL(copy_u32_kernel, dim3(16), dim3(256), 0, st, ws.h_qlist, ws.qlist, (uint64_t)na);
+    }
     if (misses > ws.miss_cap) misses = (uint32_t)ws.miss_cap;
     ISL_HIP(hipMemsetAsync(ws.uniq_count, 0, 4, st));
     hipLaunchKernelGGL(dedupe_misses_kernel, dim3((misses + 255) / 256), dim3(256), 0, st, ws.miss, misses,
-                       idx->d_present, ws.uniq, ws.uniq_count);
+                       idx->d_slot_of, ws.uniq, ws.uniq_count);
     uint32_t nu = 0;
     ISL_HIP(hipMemcpyAsync(&nu, ws.uniq_count, 4, hipMemcpyDeviceToHost, st));
     ISL_HIP(hipStreamSynchronize(st));
-    ISL_TRY(isl::encoder_embed_nodes(idx->enc, idx->d_tokens, idx->d_lens, idx->tok_L, ws.uniq, nu,
-                                     idx->enc_normalize, idx->d_emb, idx->emb_stride, st));
-    const size_t lds = (size_t)TILE_ROWS * TILE_LD * 4 + 64;
-    hipLaunchKernelGGL(row_norm2_list_kernel, dim3(std::min<uint32_t>((nu + 63) / 64, 4096)), dim3(64), lds, st,
-                       idx->d_emb, idx->emb_stride, (uint32_t)idx->emb_d, ws.uniq, nu, idx->d_norm2);
+    // slots for the new rows, round-robin over the slab (the oldest rows make room)
+    const uint32_t take = (uint32_t)std::min<uint64_t>(nu, idx->slab_rows);
+    hipLaunchKernelGGL(assign_slots_kernel, dim3((nu + 255) / 256), dim3(256), 0, st, ws.uniq, nu, take,
+                       idx->slab_head, idx->slab_rows, idx->d_slot_of, idx->d_owner, ws.uslots);
     ISL_HIP(hipGetLastError());
-    encoded += nu;
+    idx->slab_head = (idx->slab_head + take) % idx->slab_rows;
+    ISL_TRY(isl::encoder_embed_nodes(idx->enc, idx->d_tokens, idx->d_lens, idx->tok_L, ws.uniq, take,
+                                     idx->enc_normalize, idx->d_emb, idx->emb_stride, st, ws.uslots));
+    const size_t lds = (size_t)TILE_ROWS * TILE_LD * 4 + 64;
+    hipLaunchKernelGGL(row_norm2_list_kernel, dim3(std::min<uint32_t>((take + 63) / 64, 4096)), dim3(64), lds, st,
+                       idx->d_emb, idx->emb_stride, (uint32_t)idx->emb_d, ws.uslots, take, idx->d_norm2);
+    ISL_HIP(hipGetLastError());
+    encoded += take;
   }
   ws.stats.encoded_nodes = encoded;
   ws.stats.recompute_rounds = rounds;
@@ -942,9 +1019,14 @@ isl_status isl_index_prepare(isl_index* idx, uint64_t max_nq, uint64_t max_ef, u
   } release_all{idx, lanes};
   for (int i = 0; i < lanes; ++i) {
     isl::SearchWorkspace& ws = idx->ws[i];
-    ISL_TRY(prepare_workspace(ws, (uint32_t)max_nq, ovf_slots, push_log_cap((uint32_t)max_ef)));
+    ISL_TRY(prepare_workspace(ws, (uint32_t)max_nq, idx->recompute ? (uint32_t)max_nq : ovf_slots,
+                              push_log_cap((uint32_t)max_ef)));
     ISL_TRY(prepare_host_staging(ws, max_nq, d, std::max<uint64_t>(max_k, 1)));
-    if (idx->recompute) ISL_TRY(prepare_recompute(ws, max_nq));
+    if (idx->recompute) {
+      const uint32_t efm = (uint32_t)max_ef;
+      ISL_TRY(prepare_recompute(ws, max_nq, isl_launch::fast_state_words(efm <= 64 ? 1 : efm <= 128 ? 2 : efm <= 256 ? 4 : 8,
+                                                             fast_geometry(efm, (uint32_t)d).hbits)));
+    }
     if (idx->is_hnsw) ISL_TRY(ensure(ws, ws.q_entry, ws.q_entry_cap, max_nq * 2));
     if (idx->pq && idx->d_codes && !idx->is_hnsw && d == idx->pq->dimension)
       ISL_TRY(ensure(ws, ws.tl_tables, ws.tl_tables_cap, max_nq * idx->pq->m * idx->pq->K));

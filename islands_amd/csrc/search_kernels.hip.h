@@ -73,11 +73,19 @@ struct SearchParams {
   // graph under construction (build.hip): row i = adj[i * ell_w .. + ell_deg[i]), `off` unused
   uint32_t ell_w;
   const uint32_t* ell_deg;
-  // recompute provider: rows exist where `present` has a bit; a query that needs an absent row
-  // appends the id to `miss` (count in ticket[13]) and stops with QS_BLOCKED
-  const uint32_t* present;
+  // recompute provider: the rows live in a bounded slab, row of node id = slot_of[id] (kNoSlot =
+  // not materialised); a query that needs an absent row appends the id to `miss` (count in
+  // ticket[13]) and stops with QS_BLOCKED.  NULL = rows addressed by node id (in-memory provider).
+  const uint32_t* slot_of;
   uint32_t* miss;
   uint32_t miss_cap;
+  // resumable searches (recompute provider, fast kernel): a blocked query parks its state
+  // (result set, visited table, the hop in progress) in qstate and carries on from there in the
+  // next round; qlist = the queries of this round (NULL = 0 .. nq - 1)
+  uint32_t* qstate;
+  uint32_t qstate_words;  // per query
+  uint32_t* qflag;        // [all queries] 1 = state parked
+  const uint32_t* qlist;
   // HnswGraph facade (hnsw.rs): adjacency of the layers above 0 for the greedy descent
   const uint64_t* const* layer_off;  // [max_level + 1] device pointers (index 0 unused)
   const uint32_t* const* layer_adj;
@@ -467,10 +475,12 @@ __global__ __launch_bounds__(64) void hnsw_descent_kernel(SearchParams p) {
 
 // Recompute provider: true when every row of `uid` (lanes < n) is materialised; otherwise the
 // absent ids are appended to the miss list and the caller stops the query with QS_BLOCKED.
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;    // slot_of[id]: no row
+constexpr uint32_t kSlotClaim = 0xFFFFFFFEu; // transient, while a round's misses are de-duplicated
 __device__ __forceinline__ bool rows_present(const SearchParams& p, uint32_t uid, uint32_t n) {
-  if (!p.present) return true;
+  if (!p.slot_of) return true;
   const uint32_t lane = threadIdx.x;
-  const bool absent = lane < n && !((p.present[uid >> 5] >> (uid & 31)) & 1u);
+  const bool absent = lane < n && p.slot_of[uid] >= kSlotClaim;
   const uint64_t am = ballot(absent);
   if (!am) return true;
   uint32_t base = 0;
@@ -479,6 +489,11 @@ __device__ __forceinline__ bool rows_present(const SearchParams& p, uint32_t uid
   const uint32_t rank = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
   if (absent && base + rank < p.miss_cap) p.miss[base + rank] = uid;
   return false;
+}
+// row of node `id` in the provider's table (lanes >= n: any valid row)
+__device__ __forceinline__ uint32_t row_index(const SearchParams& p, uint32_t id, bool live) {
+  if (!p.slot_of) return id;
+  return live ? p.slot_of[id] : 0u;
 }
 
 // visited.insert(id) of leann.rs:933-937 for one id per lane: true when the id was not in the set.
@@ -524,9 +539,14 @@ __device__ __forceinline__ bool visited_insert(uint32_t* htab, uint32_t hbits, u
 // WIDE = adjacency rows of up to 128 ids (LeannConfig::accurate() has m0 = 96, leann.rs:419-429):
 // a lane then holds two ids of the row, and the kept neighbours of a hop are evaluated and inserted
 // 64 at a time in CSR order -- the same sequential rule, run over two slices.
-template <int S, int METRIC_API, typename ROWT, bool WIDE>
+// RESUME = searches over the recompute provider: a query that meets an absent row parks its whole
+// state and is taken up again, in the hop it stopped at, once the provider has encoded the row.
+template <int S, int METRIC_API, typename ROWT, bool WIDE, bool RESUME = false>
 __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
   constexpr uint32_t kMaxDeg = WIDE ? 128u : 64u;
+  // parked state of one query, in words: 16 scalars, tie list, the hop's unvisited ids (2 x 64),
+  // result set (S x (64 keys + 64 ids)), visited table
+  constexpr uint32_t kStTie = 16, kStHop = 80, kStR = 208, kStTab = 208 + S * 128;
   constexpr int METRIC = METRIC_API == ISL_METRIC_COSINE ? METRIC_COSINE_PRE : METRIC_API;
   const ROWT* const emb = reinterpret_cast<const ROWT*>(p.emb);
   extern __shared__ __align__(16) unsigned char smem[];
@@ -550,6 +570,10 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
     if (lane == 0) qi = atomicAdd(&p.ticket[0], 1u);
     qi = uni(qi);
     if (qi >= p.nq) break;
+    if constexpr (RESUME) {
+      if (p.qlist) qi = p.qlist[qi];
+      otab = p.otab + (size_t)qi * ocap;  // a parked query may come back on another wave
+    }
 
     if (p.q_entry && p.status[qi] != QS_OK) {  // the greedy descent already failed this query
       if (lane == 0) {
@@ -559,7 +583,14 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       continue;
     }
     const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
-    for (uint32_t i = lane; i < hcap; i += 64) htab[i] = EMPTY;
+    bool resumed = false;
+    uint32_t* qst = nullptr;
+    if constexpr (RESUME) {
+      qst = p.qstate + (size_t)qi * p.qstate_words;
+      resumed = uni(p.qflag[qi]) == 1u;
+    }
+    if (resumed) { for (uint32_t i = lane; i < hcap; i += 64) htab[i] = qst[kStTab + i]; }
+    else { for (uint32_t i = lane; i < hcap; i += 64) htab[i] = EMPTY; }
     const float q_norm = load_query<METRIC>(p.queries + (uint64_t)qi * p.d, p.d, qs);  // syncs
 
     RSet<S> rs;
@@ -577,6 +608,25 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
     uint64_t tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0, tmark = 0, ngroups = 0, nhops_rows = 0;
 #define ISL_MARK(acc) if (p.prof) { uint64_t now_ = __builtin_amdgcn_s_memrealtime(); acc += now_ - tmark; tmark = now_; }
 
+    // the hop in progress: its unvisited ids in CSR order (entry e in lane e % 64 of uid / uid_hi)
+    // and how many of them apply_pruning_strategy keeps
+    uint32_t parked_nu = 0;
+    bool have_hop = false;  // RESUME: the parked hop is evaluated before anything is popped
+    if (resumed) {
+      hcount = qst[0]; ocount = qst[1]; ovf = qst[2] != 0u; tcount = qst[3];
+      cH = qst[4]; cE = qst[5]; cV = qst[6]; cP = qst[7];
+      rs.len = qst[8]; parked_nu = qst[9];
+      t_id = qst[kStTie + lane];
+      scratch[lane] = qst[kStHop + lane];  // the parked hop's unvisited ids, where the compaction leaves them
+      scratch[64 + lane] = qst[kStHop + 64 + lane];
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        rs.kd[s] = qst[kStR + s * 128 + lane];
+        rs.id[s] = qst[kStR + s * 128 + 64 + lane];
+      }
+      have_hop = true;
+      wave_sync();
+    } else
     // entry point: provider.compute_embedding(entry) + distance, leann.rs:911-916
     if (!p.q_entry && (uint64_t)p.entry >= p.nvec) {
       status = QS_NODE_NOT_FOUND;
@@ -586,8 +636,9 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
     } else {
       // HnswGraph: the layer-0 search starts where the greedy descent (hnsw_descent_kernel) ended
       const uint32_t entry = p.q_entry ? p.q_entry[qi] : p.entry;
-      float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[entry] : 0.0f;
-      float ed = direct_distances<METRIC, ROWT>(emb, p.stride, p.d, entry, 1, qs, q_norm, e_aux);
+      const uint32_t erow = row_index(p, entry, true);
+      float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[erow] : 0.0f;
+      float ed = direct_distances<METRIC, ROWT>(emb, p.stride, p.d, erow, 1, qs, q_norm, e_aux);
       ed = rl_f(ed, 0);
       cV = p.q_entry ? p.q_evals[qi] : 1;
       if (lane == 0) htab[hslot(entry, p.hbits)] = entry;
@@ -602,6 +653,12 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
 
     if (p.prof) tmark = __builtin_amdgcn_s_memrealtime();
     while (status == QS_OK) {
+     uint32_t nu;  // unvisited neighbours of the hop
+     if constexpr (RESUME) {
+       // a parked hop: its ids are in `scratch` already; R has not changed since, so neither has :944
+       if (have_hop) { nu = parked_nu; goto hop_ready; }
+     }
+     {
       // candidates.pop(): the smallest unexpanded key of R (leann.rs:922); when none is
       // left every remaining candidate is farther than the worst result -> break (:924-928)
       uint32_t e = rs.first_unexpanded();
@@ -655,7 +712,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       if (!ovf && hcount + deg > hlimit) ovf = true;
       const bool is_new = visited_insert(htab, p.hbits, hmask, ovf, otab, p.obits, omask, nid, active);
       uint64_t nm = ballot(is_new);
-      uint32_t nu = (uint32_t)__popcll(nm);
+      nu = (uint32_t)__popcll(nm);
       bool is_new1 = false;
       uint64_t nm1 = 0;
       if constexpr (WIDE) {
@@ -677,6 +734,8 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       if (is_new) scratch[rank] = nid;
       if constexpr (WIDE)
         if (is_new1) scratch[(uint32_t)__popcll(nm) + (uint32_t)__popcll(nm1 & ((1ull << lane) - 1ull))] = nid1;
+     }
+    hop_ready:
       wave_sync();
       uint32_t uid = (uint32_t)lane < nu ? scratch[lane] : 0u;
       uint32_t uid_hi = 0u;  // entries 64.. of the list (the merge buffer reuses `scratch` below)
@@ -706,7 +765,29 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
         bool here = rows_present(p, uid, keep_all < 64 ? keep_all : 64);
         if constexpr (WIDE)
           if (keep_all > 64) here &= rows_present(p, uid_hi, keep_all - 64);
-        if (!here) { status = QS_BLOCKED; break; }
+        if (!here) {
+          status = QS_BLOCKED;
+          if constexpr (RESUME) {  // park: everything the rest of the search depends on
+            if (lane == 0) {
+              qst[0] = hcount; qst[1] = ocount; qst[2] = ovf ? 1u : 0u; qst[3] = tcount;
+              qst[4] = cH; qst[5] = cE; qst[6] = cV; qst[7] = cP;
+              qst[8] = rs.len; qst[9] = nu;
+              p.qflag[qi] = 1u;
+            }
+            qst[kStTie + lane] = t_id;
+            qst[kStHop + lane] = uid;
+            qst[kStHop + 64 + lane] = uid_hi;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+              qst[kStR + s * 128 + lane] = rs.kd[s];
+              qst[kStR + s * 128 + 64 + lane] = rs.id[s];
+            }
+            for (uint32_t i = lane; i < hcap; i += 64) qst[kStTab + i] = htab[i];
+            have_hop = true;  // (marks "parked" for the epilogue below)
+          }
+          break;
+        }
+        have_hop = false;
       }
       cV += keep_all;
       nhops_rows += 1;
@@ -717,8 +798,9 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       if constexpr (WIDE) { if (sbase) uid = uid_hi; }
       const uint32_t keep = WIDE ? (keep_all - sbase < 64 ? keep_all - sbase : 64) : keep_all;
       ngroups += (keep + 15) / 16;
-      float r_aux = (METRIC == METRIC_COSINE_PRE && (uint32_t)lane < keep) ? p.norm2[uid] : 0.0f;
-      float nd = direct_distances<METRIC, ROWT>(emb, p.stride, p.d, uid, keep, qs, q_norm, r_aux);
+      const uint32_t rix = row_index(p, uid, (uint32_t)lane < keep);
+      float r_aux = (METRIC == METRIC_COSINE_PRE && (uint32_t)lane < keep) ? p.norm2[rix] : 0.0f;
+      float nd = direct_distances<METRIC, ROWT>(emb, p.stride, p.d, rix, keep, qs, q_norm, r_aux);
       ISL_MARK(tp2)  // row fetch + distances
 
       // leann.rs:953-970 in CSR order; worst = results.peek().  NaN / -0.0 distances have no
@@ -849,7 +931,12 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
         atomicAdd(&p.ticket[payload == 5 ? 12u : payload == 6 ? 14u : 8u + ((uint32_t)payload & 3u)], 1u);
       }
     }
-    if (ovf) {  // leave the overflow table empty for the next query of this slot
+    bool parked = false;
+    if constexpr (RESUME) {
+      parked = status == QS_BLOCKED && have_hop;
+      if (!parked && lane == 0) p.qflag[qi] = 0u;  // finished, failed, or handed to the exact kernel
+    }
+    if (ovf && !parked) {  // leave the overflow table empty for the next query of this slot
       for (uint32_t i = lane; i < ocap; i += 64) otab[i] = EMPTY;
     }
     wave_sync();
@@ -939,8 +1026,9 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
       status = QS_BLOCKED;
     } else {
       uint32_t entry = p.entry;
-      float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[entry] : 0.0f;
-      float ed = rl_f(exact_rows<METRIC>(p, entry, 1, qs, tile, q_norm, e_aux), 0);
+      const uint32_t erow = row_index(p, entry, true);
+      float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[erow] : 0.0f;
+      float ed = rl_f(exact_rows<METRIC>(p, erow, 1, qs, tile, q_norm, e_aux), 0);
       cV = 1;
       if (HNSW) {
         // greedy search from the top layer down to layer 1, hnsw.rs:478-497: per round the
@@ -1054,7 +1142,7 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
         payload = first_bad;
         break;
       }
-      if (p.present) {  // recompute provider: every kept row must be materialised
+      if (p.slot_of) {  // recompute provider: every kept row must be materialised
         bool all_here = true;
         for (uint32_t base = 0; base < keep; base += 64) {
           const uint32_t R = keep - base < 64 ? keep - base : 64;
@@ -1067,8 +1155,9 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
       for (uint32_t base = 0; base < keep && status == QS_OK; base += 64) {
         uint32_t R = keep - base < 64 ? keep - base : 64;
         uint32_t uid = (uint32_t)lane < R ? ulist[base + lane] : 0u;
-        float r_aux = (METRIC == METRIC_COSINE_PRE && (uint32_t)lane < R) ? p.norm2[uid] : 0.0f;
-        float nd = exact_rows<METRIC>(p, uid, R, qs, tile, q_norm, r_aux);
+        const uint32_t rix = row_index(p, uid, (uint32_t)lane < R);
+        float r_aux = (METRIC == METRIC_COSINE_PRE && (uint32_t)lane < R) ? p.norm2[rix] : 0.0f;
+        float nd = exact_rows<METRIC>(p, rix, R, qs, tile, q_norm, r_aux);
         if ((uint32_t)lane < R) {
           dscratch[lane] = nd;
           scratch[lane] = uid;
@@ -1251,8 +1340,9 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
       status = QS_BLOCKED;
     } else {
       const uint32_t entry = p.entry;
-      const float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[entry] : 0.0f;
-      float ed = direct_distances<METRIC, ROWT>(emb, p.stride, p.d, entry, 1, qs, q_norm, e_aux);
+      const uint32_t erow = row_index(p, entry, true);
+      const float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[erow] : 0.0f;
+      float ed = direct_distances<METRIC, ROWT>(emb, p.stride, p.d, erow, 1, qs, q_norm, e_aux);
       ed = rl_f(ed, 0);
       cV = 1;
       if (lane == 0) {
@@ -1390,8 +1480,9 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
         }
         if (!rows_present(p, pid, pc)) { status = QS_BLOCKED; return; }
         cV += pc;
-        const float r_aux = (METRIC == METRIC_COSINE_PRE && lane < pc) ? p.norm2[pid] : 0.0f;
-        const float nd = direct_distances<METRIC, ROWT>(emb, p.stride, p.d, pid, pc, qs, q_norm, r_aux);
+        const uint32_t prow = row_index(p, pid, lane < pc);
+        const float r_aux = (METRIC == METRIC_COSINE_PRE && lane < pc) ? p.norm2[prow] : 0.0f;
+        const float nd = direct_distances<METRIC, ROWT>(emb, p.stride, p.d, prow, pc, qs, q_norm, r_aux);
         const uint64_t rkey = ((uint64_t)ordkey(nd) << 32) | ((uint64_t)pid << 1);
         rlen = tl_merge(res, rlen, rkey, pc, nbuf);
         if (rlen > ef) rlen = ef;  // lines 26-27
@@ -1468,10 +1559,13 @@ void launch_one(K kernel, uint32_t grid, size_t lds, hipStream_t st, const Searc
 // Launchers defined in the instantiating units; `params` points at a SearchParams (the struct is
 // the same text in every unit).
 namespace isl_launch {
-void launch_fast_s1(int metric, bool wide, bool bf16, uint32_t grid, size_t lds, hipStream_t st, const void* params);
-void launch_fast_s2(int metric, bool wide, bool bf16, uint32_t grid, size_t lds, hipStream_t st, const void* params);
-void launch_fast_s4(int metric, bool wide, bool bf16, uint32_t grid, size_t lds, hipStream_t st, const void* params);
-void launch_fast_s8(int metric, bool wide, bool bf16, uint32_t grid, size_t lds, hipStream_t st, const void* params);
+// resume = the RESUME instantiation (recompute provider; f32 rows only)
+void launch_fast_s1(int metric, bool wide, bool bf16, bool resume, uint32_t grid, size_t lds, hipStream_t st, const void* params);
+void launch_fast_s2(int metric, bool wide, bool bf16, bool resume, uint32_t grid, size_t lds, hipStream_t st, const void* params);
+void launch_fast_s4(int metric, bool wide, bool bf16, bool resume, uint32_t grid, size_t lds, hipStream_t st, const void* params);
+void launch_fast_s8(int metric, bool wide, bool bf16, bool resume, uint32_t grid, size_t lds, hipStream_t st, const void* params);
+// words of one parked query (RESUME) for result sets of S x 64 entries and a visited table of 1 << hbits
+inline uint32_t fast_state_words(int S, uint32_t hbits) { return 208u + (uint32_t)S * 128u + (1u << hbits); }
 void launch_exact(int metric, bool hnsw, uint32_t grid, size_t lds, hipStream_t st, const void* params);
 void launch_two_level(int metric, bool bf16, uint32_t grid, size_t lds, hipStream_t st, const void* params);
 void launch_descent(int metric, uint32_t grid, size_t lds, hipStream_t st, const void* params);

@@ -151,6 +151,39 @@ def test_recompute_provider_equals_in_memory_provider(orc):
         assert got[0][i, :c].tolist() == r.ids.tolist()
 
 
+def test_recompute_provider_small_row_cache(orc):
+    """Recompute mode stores no embeddings (leann.rs:366-371): the provider's row cache is a bounded
+    slab.  With room for a quarter of the nodes rows get evicted and re-encoded inside one call,
+    parked queries resume where they stopped -- and ids, distance bits and counters still equal the
+    in-memory provider's.  ef = 300 and rows past 64 ids take the other instantiations."""
+    cfg, enc, tok, lens, emb = _recompute_case(orc, n=1600, seed=11)
+    n = emb.shape[0]
+    from _data import random_csr
+    q = emb[::53] + np.float32(0.02)
+    for (deg, ef, rows) in ((20, 48, 400), (90, 300, 600)):
+        off, nb = random_csr(n, deg, 3)
+        csr = orc.Csr(off, nb, entry_point=5)
+        g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels, entry_point=5,
+                        num_nodes=n, degree_counts=csr.degree_counts)
+        mem_idx = ia.LeannIndex.from_csr(g, None, dimension=64).upload(0)
+        mem_idx.set_embeddings(emb)
+        want = mem_idx.search_batch(q, 10, ef)
+        want_stats = mem_idx.last_stats()
+        rec_idx = ia.LeannIndex.from_csr(g, None, dimension=64).upload(0)
+        rec_idx.set_recompute_provider(enc, tok, lens, cache_rows=rows)
+        assert rec_idx.recompute_cache_bytes() < n * 64 * 4 // 2
+        got = rec_idx.search_batch(q, 10, ef)
+        st = rec_idx.last_stats()
+        assert got[2].tolist() == want[2].tolist() and got[0].tolist() == want[0].tolist()
+        assert got[1].view(np.uint32).tolist() == want[1].view(np.uint32).tolist()
+        for f in ("expansions", "edges", "evals", "pushes"):
+            assert st[f] == want_stats[f], f
+        assert st["encoded_nodes"] >= rows  # the slab turned over at least once
+        # a parked query advances one hop per round: rounds follow the longest query, not the batch
+        longest = max(orc.leann_search(csr, emb, q[i], 10, ef).counters["expansions"] for i in range(q.shape[0]))
+        assert st["recompute_rounds"] <= 2 * longest + 8, (st["recompute_rounds"], longest)
+
+
 def test_recompute_provider_keeps_rows_when_asked(orc):
     cfg, enc, tok, lens, emb = _recompute_case(orc, n=400, seed=9)
     levels = np.zeros(400, np.uint64)
