@@ -276,6 +276,8 @@ void isl_index_free(isl_index* idx) {
     if (idx->d_lens) (void)hipFree(idx->d_lens);
     if (idx->d_slot_of) (void)hipFree(idx->d_slot_of);
     if (idx->d_owner) (void)hipFree(idx->d_owner);
+    if (idx->d_stamp) (void)hipFree(idx->d_stamp);
+    if (idx->d_slab_head) (void)hipFree(idx->d_slab_head);
     if (idx->d_off) (void)hipFree(idx->d_off);
     if (idx->d_adj) (void)hipFree(idx->d_adj);
     if (idx->d_emb) (void)hipFree(idx->d_emb);
@@ -783,12 +785,12 @@ isl_status isl_set_embeddings(isl_index* idx, const void* rows, uint64_t n, uint
 
 // (re)allocates the recompute provider's row cache: slab, per-slot norms, slot map, owners
 static isl_status alloc_recompute_cache(isl_index* idx, uint64_t rows) {
-  void* olds[] = {idx->d_emb, idx->d_norm2, idx->d_slot_of, idx->d_owner};
+  void* olds[] = {idx->d_emb, idx->d_norm2, idx->d_slot_of, idx->d_owner, idx->d_stamp, idx->d_slab_head};
   for (void* p : olds)
     if (p) (void)hipFree(p);
   idx->d_emb = nullptr; idx->d_norm2 = nullptr; idx->d_slot_of = nullptr; idx->d_owner = nullptr;
+  idx->d_stamp = nullptr; idx->d_slab_head = nullptr;
   idx->slab_rows = 0;
-  idx->slab_head = 0;
   const uint64_t stride = idx->emb_stride, n = idx->nvec;
   ISL_HIP(hipMalloc(&idx->d_emb, (size_t)(rows * stride + 256) * sizeof(float)));
   ISL_HIP(hipMemset(idx->d_emb, 0, (size_t)(rows * stride + 256) * sizeof(float)));
@@ -798,6 +800,10 @@ static isl_status alloc_recompute_cache(isl_index* idx, uint64_t rows) {
   ISL_HIP(hipMemset(idx->d_slot_of, 0xFF, (size_t)(n + 1) * 4));
   ISL_HIP(hipMalloc(&idx->d_owner, (size_t)rows * 4));
   ISL_HIP(hipMemset(idx->d_owner, 0xFF, (size_t)rows * 4));
+  ISL_HIP(hipMalloc(&idx->d_stamp, (size_t)rows * 4));
+  ISL_HIP(hipMemset(idx->d_stamp, 0, (size_t)rows * 4));
+  ISL_HIP(hipMalloc(&idx->d_slab_head, 8));  // [0] clock hand, [1] slots used so far
+  ISL_HIP(hipMemset(idx->d_slab_head, 0, 8));
   idx->slab_rows = rows;
   return ISL_OK;
 }
@@ -816,7 +822,7 @@ isl_status isl_index_set_recompute_cache_rows(isl_index* idx, uint64_t rows) {
 
 uint64_t isl_index_recompute_cache_bytes(const isl_index* idx) {
   if (!idx || !idx->recompute) return 0;
-  return (idx->slab_rows * idx->emb_stride + 256) * 4 + idx->slab_rows * 8 + (idx->nvec + 1) * 4;
+  return (idx->slab_rows * idx->emb_stride + 256) * 4 + idx->slab_rows * 12 + (idx->nvec + 1) * 4;
 }
 
 // EmbeddingProvider backed by the encoder (recompute mode), see islands_amd.h.
@@ -839,11 +845,13 @@ isl_status isl_set_recompute_provider(isl_index* idx, isl_encoder* enc, const ui
   const uint64_t d = enc->cfg.hidden, stride = (d + 3) / 4 * 4;
   // (d_emb16 too: bf16 rows of an earlier in-memory provider would otherwise stay the table the
   // searches read)
-  void* olds[] = {idx->d_emb, idx->d_emb16, idx->d_norm2, idx->d_tokens, idx->d_lens, idx->d_slot_of, idx->d_owner};
+  void* olds[] = {idx->d_emb, idx->d_emb16, idx->d_norm2, idx->d_tokens, idx->d_lens, idx->d_slot_of, idx->d_owner,
+                  idx->d_stamp, idx->d_slab_head};
   for (void* p : olds)
     if (p) (void)hipFree(p);
   idx->d_emb = nullptr; idx->d_emb16 = nullptr; idx->d_norm2 = nullptr; idx->d_tokens = nullptr;
-  idx->d_lens = nullptr; idx->d_slot_of = nullptr; idx->d_owner = nullptr;
+  idx->d_lens = nullptr; idx->d_slot_of = nullptr; idx->d_owner = nullptr; idx->d_stamp = nullptr;
+  idx->d_slab_head = nullptr;
   free_exact_pool(idx->pool);
   idx->recompute = false;
   // Recompute mode does not store embeddings (leann.rs:366-371): what is resident is the token

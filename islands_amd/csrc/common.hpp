@@ -202,8 +202,10 @@ struct isl_index {
   // oldest rows make room once the slab is full
   uint32_t* d_slot_of = nullptr;       // [nvec]
   uint32_t* d_owner = nullptr;         // [slab_rows]
+  uint32_t* d_stamp = nullptr;         // [slab_rows] round in which a row was last asked for
+  uint32_t* d_slab_head = nullptr;     // [1] where the clock hand of the slot allocator stands
   uint64_t slab_rows = 0;
-  mutable uint64_t slab_head = 0;      // next slot to hand out (under recompute_mu)
+  mutable uint32_t round_no = 1;       // rounds of recompute searches so far (under recompute_mu)
   bool recompute = false, keep_rows = false;
   int32_t enc_normalize = 1;
 

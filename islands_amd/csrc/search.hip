@@ -448,6 +448,8 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   p.pool_locks = idx->pool.locks;
   p.pool_slots = idx->pool.slots;
   p.slot_of = idx->recompute ? idx->d_slot_of : nullptr;
+  p.stamp = idx->d_stamp;
+  p.round_no = idx->round_no;
   if (resume) {
     p.qstate = ws.qstate;
     p.qstate_words = isl_launch::fast_state_words(ef <= 64 ? 1 : ef <= 128 ? 2 : ef <= 256 ? 4 : 8, fg.hbits);
@@ -654,22 +656,57 @@ __global__ void dedupe_misses_kernel(const uint32_t* __restrict__ miss, uint32_t
   if (atomicCAS(&slot_of[id], kNoSlot, kSlotClaim) == kNoSlot) uniq[atomicAdd(uniq_count, 1u)] = id;
 }
 
-// Hands the round's unique misses their slab slots, round-robin from `head`: the node that held a
-// slot before loses its row (its map entry goes back to "absent").  Misses beyond `take` (more
-// than the slab can hold at once) are un-claimed and reported again next round.
-__global__ void assign_slots_kernel(const uint32_t* __restrict__ uniq, uint32_t n, uint32_t take, uint64_t head,
-                                    uint64_t slab_rows, uint32_t* __restrict__ slot_of,
-                                    uint32_t* __restrict__ owner, uint32_t* __restrict__ uslots) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t id = uniq[i];
-  if (i >= take) { slot_of[id] = kNoSlot; return; }
-  const uint32_t s = (uint32_t)((head + i) % slab_rows);
-  const uint32_t old = owner[s];
-  if (old != kNoSlot) slot_of[old] = kNoSlot;  // (never one of this round's ids: those were absent)
-  owner[s] = id;
-  slot_of[id] = s;
-  uslots[i] = s;
+// Hands the round's unique misses their slab slots (one wave): once the slab is full a clock hand walks it and
+// skips the rows some query asked for in this round (stamp == round) -- those belong to hops that
+// are waiting for their last rows, evicting them would make the hop wait for THEM next round.  The
+// node that held a slot before loses its row.  Ids left over when a full turn finds no more free
+// slots are un-claimed and reported again next round.
+__global__ __launch_bounds__(64) void assign_slots_kernel(const uint32_t* __restrict__ uniq,
+                                                          const uint32_t* __restrict__ n_ptr,
+                                                          uint32_t round_no, uint32_t slab_rows,
+                                                          uint32_t* __restrict__ head_word,
+                                                          uint32_t* __restrict__ slot_of, uint32_t* __restrict__ owner,
+                                                          uint32_t* __restrict__ stamp, uint32_t* __restrict__ uslots,
+                                                          uint32_t* __restrict__ taken) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t n = *n_ptr;
+  // never-used slots first (head_word[1] counts them): nothing is evicted before the slab is full
+  uint32_t fill = head_word[1], done = 0;
+  {
+    const uint32_t t = n < slab_rows - fill ? n : slab_rows - fill;
+    for (uint32_t i = lane; i < t; i += 64) {
+      const uint32_t id = uniq[i], s = fill + i;
+      owner[s] = id;
+      slot_of[id] = s;
+      stamp[s] = round_no;
+      uslots[i] = s;
+    }
+    done = t;
+    fill += t;
+  }
+  uint32_t pos = *head_word % slab_rows, walked = 0;
+  while (done < n && walked < slab_rows) {
+    const uint32_t step = slab_rows - walked < 64u ? slab_rows - walked : 64u;
+    const uint32_t s = (pos + lane) % slab_rows;
+    const bool free_ = lane < step && stamp[s] != round_no;
+    const uint64_t fm = ballot(free_);
+    const uint32_t i = done + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
+    if (free_ && i < n) {
+      const uint32_t id = uniq[i];
+      const uint32_t old = owner[s];
+      if (old != kNoSlot) slot_of[old] = kNoSlot;  // (never one of this round's ids: those were absent)
+      owner[s] = id;
+      slot_of[id] = s;
+      stamp[s] = round_no;
+      uslots[i] = s;
+    }
+    done += (uint32_t)__popcll(fm);
+    pos = (pos + step) % slab_rows;
+    walked += step;
+  }
+  if (done > n) done = n;
+  for (uint32_t i = done + lane; i < n; i += 64) slot_of[uniq[i]] = kNoSlot;
+  if (lane == 0) { head_word[0] = pos; head_word[1] = fill; *taken = done; }
 }
 
 // norm2[id] = sum_j row[id][j]^2 in the reference's order for the freshly encoded rows
@@ -751,20 +788,35 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
   if (!idx->keep_rows) {  // every call starts from an empty cache: each node is encoded once per call
     ISL_HIP(hipMemsetAsync(idx->d_slot_of, 0xFF, (idx->nvec + 1) * 4, st));
     ISL_HIP(hipMemsetAsync(idx->d_owner, 0xFF, idx->slab_rows * 4, st));
-    idx->slab_head = 0;
+    ISL_HIP(hipMemsetAsync(idx->d_stamp, 0, idx->slab_rows * 4, st));
+    ISL_HIP(hipMemsetAsync(idx->d_slab_head, 0, 8, st));
   }
   ISL_HIP(hipMemsetAsync(ws.qflag, 0, nq * 4, st));
   uint64_t encoded = 0, rounds = 0;
   double kernel_ms = 0.0;
-  uint32_t active = (uint32_t)nq;
-  bool listed = false;
+  // Queries in flight at a time: each may hold one hop (<= 128 rows) waiting for its last rows, and
+  // those rows are exempt from eviction -- half the slab stays free for the rows being encoded, so
+  // every round serves every miss and every query in flight advances by a hop per round.  (2^20
+  // rows: 4096 queries; a smaller cache works through the batch a few queries at a time.)
+  // (A slab with a row for every node never evicts: no limit.)
+  const uint32_t max_active = (resumable && idx->slab_rows < idx->nvec)
+                                  ? (uint32_t)std::max<uint64_t>(1, idx->slab_rows / 256) : (uint32_t)nq;
+  uint32_t active = (uint32_t)std::min<uint64_t>(nq, max_active);
+  uint32_t next_fresh = active;  // queries [next_fresh, nq) have not been started
+  bool listed = active < nq;
+  if (listed) {
+    for (uint32_t i = 0; i < active; ++i) ws.h_qlist[i] = i;
+    hipLaunchKernelGGL(copy_u32_kernel, dim3(16), dim3(256), 0, st, ws.h_qlist, ws.qlist, (uint64_t)active);
+  }
   struct RoundReset {  // the lane goes back with its round fields cleared whatever happens below
     isl::SearchWorkspace& w;
     ~RoundReset() { w.round_active = 0; w.round_listed = false; }
   } reset{ws};
+  uint32_t* h_taken = ws.h_head + 15;  // (word 15 of the pinned ticket mirror is otherwise unused)
   for (;;) {
     ws.round_active = resumable ? active : 0u;
     ws.round_listed = listed;
+    idx->round_no += 1;
     ISL_TRY(search_enqueue(idx, ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, user_stream, mode, tl));
     uint32_t misses = 0;
     bool window_short = false;
@@ -773,36 +825,42 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
     ISL_TRY(fst);
     kernel_ms += ws.stats.kernel_ms;
     rounds += 1;
-    if (!misses) break;
-    if (rounds > 200000)
-      return isl::fail(ISL_ERR_SEARCH, "Search error: the recompute provider's row cache (%llu rows) is too small "
-                       "for this batch", (unsigned long long)idx->slab_rows);
-    if (resumable) {  // next round: the queries that are waiting for rows
+    if (resumable) {  // next round: the queries that are waiting for rows, topped up with fresh ones
       uint32_t na = 0;
-      for (uint64_t i = 0; i < nq; ++i)
+      for (uint64_t i = 0; i < next_fresh; ++i)
         if (ws.h_status[i] == QS_BLOCKED) ws.h_qlist[na++] = (uint32_t)i;
+      while (na < max_active && next_fresh < nq) ws.h_qlist[na++] = next_fresh++;
       active = na;
       listed = true;
+      if (!active) break;
       hipLaunchKernelGGL(copy_u32_kernel, dim3(16), dim3(256), 0, st, ws.h_qlist, ws.qlist, (uint64_t)na);
+    } else if (!misses) {
+      break;
     }
+    if (rounds > 200000)
+      return isl::fail(ISL_ERR_SEARCH, "Search error: the recompute provider's row cache (%llu rows) is too small "
+                       "for this batch (queries answered by the heap-exact or the two-level kernel re-run from "
+                       "their start and need the rows of their whole traversal resident)",
+                       (unsigned long long)idx->slab_rows);
+    if (!misses) continue;  // only fresh queries to start
     if (misses > ws.miss_cap) misses = (uint32_t)ws.miss_cap;
     ISL_HIP(hipMemsetAsync(ws.uniq_count, 0, 4, st));
     hipLaunchKernelGGL(dedupe_misses_kernel, dim3((misses + 255) / 256), dim3(256), 0, st, ws.miss, misses,
                        idx->d_slot_of, ws.uniq, ws.uniq_count);
-    uint32_t nu = 0;
-    ISL_HIP(hipMemcpyAsync(&nu, ws.uniq_count, 4, hipMemcpyDeviceToHost, st));
-    ISL_HIP(hipStreamSynchronize(st));
-    // slots for the new rows, round-robin over the slab (the oldest rows make room)
-    const uint32_t take = (uint32_t)std::min<uint64_t>(nu, idx->slab_rows);
-    hipLaunchKernelGGL(assign_slots_kernel, dim3((nu + 255) / 256), dim3(256), 0, st, ws.uniq, nu, take,
-                       idx->slab_head, idx->slab_rows, idx->d_slot_of, idx->d_owner, ws.uslots);
+    // slots for the new rows (clock hand over the slab; rows asked for in this round stay)
+    hipLaunchKernelGGL(assign_slots_kernel, dim3(1), dim3(64), 0, st, ws.uniq, ws.uniq_count, idx->round_no,
+                       (uint32_t)idx->slab_rows, idx->d_slab_head, idx->d_slot_of, idx->d_owner, idx->d_stamp,
+                       ws.uslots, ws.ticket + 15);
     ISL_HIP(hipGetLastError());
-    idx->slab_head = (idx->slab_head + take) % idx->slab_rows;
+    hipLaunchKernelGGL(copy_u32_kernel, dim3(1), dim3(64), 0, st, ws.ticket + 15, h_taken, (uint64_t)1);
+    ISL_HIP(hipStreamSynchronize(st));
+    const uint32_t take = *h_taken;
     ISL_TRY(isl::encoder_embed_nodes(idx->enc, idx->d_tokens, idx->d_lens, idx->tok_L, ws.uniq, take,
                                      idx->enc_normalize, idx->d_emb, idx->emb_stride, st, ws.uslots));
     const size_t lds = (size_t)TILE_ROWS * TILE_LD * 4 + 64;
-    hipLaunchKernelGGL(row_norm2_list_kernel, dim3(std::min<uint32_t>((take + 63) / 64, 4096)), dim3(64), lds, st,
-                       idx->d_emb, idx->emb_stride, (uint32_t)idx->emb_d, ws.uslots, take, idx->d_norm2);
+    if (take)
+      hipLaunchKernelGGL(row_norm2_list_kernel, dim3(std::min<uint32_t>((take + 63) / 64, 4096)), dim3(64), lds, st,
+                         idx->d_emb, idx->emb_stride, (uint32_t)idx->emb_d, ws.uslots, take, idx->d_norm2);
     ISL_HIP(hipGetLastError());
     encoded += take;
   }

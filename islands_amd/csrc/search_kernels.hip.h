@@ -77,6 +77,8 @@ struct SearchParams {
   // not materialised); a query that needs an absent row appends the id to `miss` (count in
   // ticket[13]) and stops with QS_BLOCKED.  NULL = rows addressed by node id (in-memory provider).
   const uint32_t* slot_of;
+  uint32_t* stamp;     // [slab rows] round in which the row was last asked for: such rows are not evicted
+  uint32_t round_no;
   uint32_t* miss;
   uint32_t miss_cap;
   // resumable searches (recompute provider, fast kernel): a blocked query parks its state
@@ -480,7 +482,9 @@ constexpr uint32_t kSlotClaim = 0xFFFFFFFEu; // transient, while a round's misse
 __device__ __forceinline__ bool rows_present(const SearchParams& p, uint32_t uid, uint32_t n) {
   if (!p.slot_of) return true;
   const uint32_t lane = threadIdx.x;
-  const bool absent = lane < n && p.slot_of[uid] >= kSlotClaim;
+  const uint32_t sl = lane < n ? p.slot_of[uid] : 0u;
+  const bool absent = lane < n && sl >= kSlotClaim;
+  if (lane < n && !absent) p.stamp[sl] = p.round_no;  // in use this round, whether or not the hop can run yet
   const uint64_t am = ballot(absent);
   if (!am) return true;
   uint32_t base = 0;
@@ -488,6 +492,30 @@ __device__ __forceinline__ bool rows_present(const SearchParams& p, uint32_t uid
   base = uni(base);
   const uint32_t rank = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
   if (absent && base + rank < p.miss_cap) p.miss[base + rank] = uid;
+  return false;
+}
+// The same for a hop of up to 128 rows (entry e in lane e % 64 of uid_lo / uid_hi): ONE run of the
+// miss list per hop -- the provider serves a prefix of the list when its row cache is small, and a
+// hop whose rows arrive in two rounds could lose the first part again before the second is there.
+__device__ __forceinline__ bool rows_present2(const SearchParams& p, uint32_t uid_lo, uint32_t n_lo,
+                                              uint32_t uid_hi, uint32_t n_hi) {
+  if (!p.slot_of) return true;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t s_lo = lane < n_lo ? p.slot_of[uid_lo] : 0u, s_hi = lane < n_hi ? p.slot_of[uid_hi] : 0u;
+  const bool a_lo = lane < n_lo && s_lo >= kSlotClaim;
+  const bool a_hi = lane < n_hi && s_hi >= kSlotClaim;
+  if (lane < n_lo && !a_lo) p.stamp[s_lo] = p.round_no;
+  if (lane < n_hi && !a_hi) p.stamp[s_hi] = p.round_no;
+  const uint64_t m_lo = ballot(a_lo), m_hi = ballot(a_hi);
+  if (!(m_lo | m_hi)) return true;
+  const uint32_t c_lo = (uint32_t)__popcll(m_lo);
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(&p.ticket[13], c_lo + (uint32_t)__popcll(m_hi));
+  base = uni(base);
+  const uint64_t below = (1ull << lane) - 1ull;
+  if (a_lo && base + (uint32_t)__popcll(m_lo & below) < p.miss_cap) p.miss[base + (uint32_t)__popcll(m_lo & below)] = uid_lo;
+  if (a_hi && base + c_lo + (uint32_t)__popcll(m_hi & below) < p.miss_cap)
+    p.miss[base + c_lo + (uint32_t)__popcll(m_hi & below)] = uid_hi;
   return false;
 }
 // row of node `id` in the provider's table (lanes >= n: any valid row)
@@ -762,9 +790,9 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
         }
       }
       {
-        bool here = rows_present(p, uid, keep_all < 64 ? keep_all : 64);
-        if constexpr (WIDE)
-          if (keep_all > 64) here &= rows_present(p, uid_hi, keep_all - 64);
+        bool here;
+        if constexpr (WIDE) here = rows_present2(p, uid, keep_all < 64 ? keep_all : 64, uid_hi, keep_all > 64 ? keep_all - 64 : 0);
+        else here = rows_present(p, uid, keep_all);
         if (!here) {
           status = QS_BLOCKED;
           if constexpr (RESUME) {  // park: everything the rest of the search depends on

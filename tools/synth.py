@@ -147,6 +147,12 @@ def recall_at_k(found_ids: torch.Tensor, found_cnt: torch.Tensor, truth_ids: tor
 
 # ------------------------------------------------------------------ graph builder
 @torch.no_grad()
+# dtype of the k-means / bucket ASSIGNMENT GEMMs (build_graph(precise=True) switches to float32:
+# embeddings with a large common component -- a randomly initialised encoder's -- differ from each
+# other only past bfloat16's 8 bits)
+_ASSIGN_DTYPE = torch.bfloat16
+
+
 def _knn_in_buckets(x, member_ids, bucket_off, k, mem_budget=1.5e9):
     """For every (point, bucket) membership: the k nearest OTHER members of that bucket.
     member_ids: int64 [P] point ids grouped by bucket; bucket_off: int64 [B+1].
@@ -230,10 +236,10 @@ def _medoids(x, ids, C, chunk=1 << 18):
     k = C.shape[0]
     best_s = torch.full((k,), -3.0, device=dev)
     best_i = torch.zeros(k, dtype=torch.int64, device=dev)
-    Ch = C.to(torch.bfloat16)
+    Ch = C.to(_ASSIGN_DTYPE)
     for s0 in range(0, ids.numel(), chunk):
         sub = ids[s0:s0 + chunk]
-        sim = (x[sub].to(torch.bfloat16) @ Ch.T).float()
+        sim = (x[sub].to(_ASSIGN_DTYPE) @ Ch.T).float()
         sv, si = sim.max(0)
         upd = sv > best_s
         best_s = torch.where(upd, sv, best_s)
@@ -253,12 +259,12 @@ def _lloyd_centroids(x, n_cent, iters=3, seed=11, chunk=1 << 18, ids=None):
     g.manual_seed(seed)
     C = x[torch.randperm(n, generator=g, device=dev)[:n_cent]].clone()
     for _ in range(iters):
-        Ch = C.to(torch.bfloat16)
+        Ch = C.to(_ASSIGN_DTYPE)
         sums = torch.zeros_like(C)
         cnt = torch.zeros(n_cent, device=dev)
         for s0 in range(0, n, chunk):
             xb = x[s0:s0 + chunk]
-            a = torch.argmax(xb.to(torch.bfloat16) @ Ch.T, dim=1)
+            a = torch.argmax(xb.to(_ASSIGN_DTYPE) @ Ch.T, dim=1)
             # deterministic segmented sums (index_add_ uses float atomics: run-to-run noise
             # would change the buckets and with them the graph)
             order = torch.argsort(a, stable=True)
@@ -287,9 +293,9 @@ def _knn_subset(x, ids, k, centroids=None, assign_chunk=1 << 18, exact_limit=400
     C = centroids
     a1 = torch.empty(n, dtype=torch.int64, device=dev)
     a2 = torch.empty(n, dtype=torch.int64, device=dev)
-    Ch = C.to(torch.bfloat16)
+    Ch = C.to(_ASSIGN_DTYPE)
     for s in range(0, n, assign_chunk):
-        sim = x[ids[s:s + assign_chunk]].to(torch.bfloat16) @ Ch.T
+        sim = x[ids[s:s + assign_chunk]].to(_ASSIGN_DTYPE) @ Ch.T
         top = torch.topk(sim.float(), 2, dim=1).indices
         a1[s:s + assign_chunk], a2[s:s + assign_chunk] = top[:, 0], top[:, 1]
     nC = C.shape[0]
@@ -368,7 +374,19 @@ def _nearest_parent(x, child_ids, parent_ids, npar=2, chunk=1 << 16):
 
 @torch.no_grad()
 def build_graph(x: torch.Tensor, m0: int = 60, k0: int = 28, k_upper: int = 20, pool: int = 96,
-                child_cap: int = 30, seed: int = 7, level_ratio: int = 32):
+                child_cap: int = 30, seed: int = 7, level_ratio: int = 32, precise: bool = False):
+    global _ASSIGN_DTYPE
+    saved = _ASSIGN_DTYPE
+    _ASSIGN_DTYPE = torch.float32 if precise else torch.bfloat16
+    try:
+        return _build_graph(x, m0, k0, k_upper, pool, child_cap, seed, level_ratio)
+    finally:
+        _ASSIGN_DTYPE = saved
+
+
+@torch.no_grad()
+def _build_graph(x: torch.Tensor, m0: int = 60, k0: int = 28, k_upper: int = 20, pool: int = 96,
+                 child_cap: int = 30, seed: int = 7, level_ratio: int = 32):
     """Flattened hierarchical proximity graph over the rows of x (L2-normalised, cosine).
     Returns (offsets int64 [n+1], neighbours int32 [nnz], entry_point int).
 
