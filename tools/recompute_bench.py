@@ -7,9 +7,9 @@ Prints one JSON line: queries/s, recall@10, encoder throughput as a fraction of 
 rounds, the provider's HBM footprint next to what a dense N x d table would take.
 
 Synthetic data (no checkpoint or corpus can be fetched): node i's "text" follows the same tree of
-clusters as the headline rows (branching 10, 1000 nodes per leaf) -- 8 tokens per tree level that
-depend on the node's path prefix at that level, the rest noise tokens -- so that embeddings of
-nodes that share more of their path are closer; weights ~ N(0, 0.02^2).
+clusters as the headline rows (branching 10, 1000 nodes per leaf) -- 4 tokens for each upper tree
+level and 28 for the leaf, all hashed from the node's path prefix at that level, the other 24 noise
+tokens -- so that embeddings of nodes that share more of their path are closer; weights ~ N(0, 0.02^2).
 The graph comes from the harness of tools/synth.py run on the embeddings the encoder itself
 produces (all nodes encoded once, untimed set-up; the recompute index keeps none of them), with
 its k-means assignments in float32: a randomly initialised encoder puts a large common component
@@ -43,16 +43,18 @@ def log(msg):
 
 
 def path_tokens(ids: torch.Tensor, L: int, vocab: int, per_leaf: int, seed: int, noise_seed: int):
-    """[len(ids), L] int64 token rows: 8 tokens for each of 4 tree levels (a hash of the node's path
-    prefix at that level: leaf // 1000, // 100, // 10, // 1 -- branching 10), then noise tokens
-    hashed from (node id, noise_seed), so that any id range can be produced independently."""
+    """[len(ids), L] int64 token rows: 4 tokens for each of the three upper tree levels and 28 for
+    the leaf (a hash of the node's path prefix at that level: leaf // 1000, // 100, // 10, // 1 --
+    branching 10), then noise tokens hashed from (node id, noise_seed), so that any id range can be
+    produced independently.  Leaf-mates share 40 of 64 tokens, nodes of sibling leaves 12: like the
+    headline rows, a query's nearest neighbours are in its own leaf."""
     dev = ids.device
     leaf = ids // per_leaf
     out = torch.empty((ids.numel(), L), dtype=torch.int64, device=dev)
     col = 0
-    for li, div in enumerate((1000, 100, 10, 1)):
+    for li, (div, cnt) in enumerate(((1000, 4), (100, 4), (10, 4), (1, 28))):
         pref = leaf // div
-        for j in range(8):
+        for j in range(cnt):
             if col >= L:
                 break
             hsh = (pref * 1000003 + (li * 8 + j) * 7919 + seed * 104729) % 2147483647

@@ -146,13 +146,13 @@ def recall_at_k(found_ids: torch.Tensor, found_cnt: torch.Tensor, truth_ids: tor
 
 
 # ------------------------------------------------------------------ graph builder
-@torch.no_grad()
 # dtype of the k-means / bucket ASSIGNMENT GEMMs (build_graph(precise=True) switches to float32:
 # embeddings with a large common component -- a randomly initialised encoder's -- differ from each
 # other only past bfloat16's 8 bits)
 _ASSIGN_DTYPE = torch.bfloat16
 
 
+@torch.no_grad()
 def _knn_in_buckets(x, member_ids, bucket_off, k, mem_budget=1.5e9):
     """For every (point, bucket) membership: the k nearest OTHER members of that bucket.
     member_ids: int64 [P] point ids grouped by bucket; bucket_off: int64 [B+1].
@@ -257,7 +257,7 @@ def _lloyd_centroids(x, n_cent, iters=3, seed=11, chunk=1 << 18, ids=None):
     n, d = x.shape
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
-    C = x[torch.randperm(n, generator=g, device=dev)[:n_cent]].clone()
+    C = x[torch.randperm(n, generator=g, device=dev)[:n_cent]].float().clone()  # (x may be bf16 rows)
     for _ in range(iters):
         Ch = C.to(_ASSIGN_DTYPE)
         sums = torch.zeros_like(C)
@@ -269,7 +269,7 @@ def _lloyd_centroids(x, n_cent, iters=3, seed=11, chunk=1 << 18, ids=None):
             # would change the buckets and with them the graph)
             order = torch.argsort(a, stable=True)
             lens = torch.bincount(a, minlength=n_cent)
-            part = torch.segment_reduce(xb[order], "sum", lengths=lens, unsafe=True)
+            part = torch.segment_reduce(xb[order].float(), "sum", lengths=lens, unsafe=True)
             sums += part
             cnt += lens.to(torch.float32)
         alive = cnt > 0
@@ -368,7 +368,7 @@ def _nearest_parent(x, child_ids, parent_ids, npar=2, chunk=1 << 16):
     npar = min(npar, parent_ids.numel())
     out = torch.empty((child_ids.numel(), npar), dtype=torch.int64, device=x.device)
     for s0 in range(0, child_ids.numel(), chunk):
-        out[s0:s0 + chunk] = torch.topk(x[child_ids[s0:s0 + chunk]] @ P.T, npar, dim=1).indices
+        out[s0:s0 + chunk] = torch.topk((x[child_ids[s0:s0 + chunk]] @ P.T).float(), npar, dim=1).indices
     return out
 
 
@@ -477,7 +477,7 @@ def _build_graph(x: torch.Tensor, m0: int = 60, k0: int = 28, k_upper: int = 20,
             par2 = _nearest_parent(x, ids, parents)
             par = par2.reshape(-1)
             chd = ids[:, None].expand_as(par2).reshape(-1)
-            sim = (x[chd] * x[parents[par]]).sum(1)
+            sim = (x[chd].float() * x[parents[par]].float()).sum(1)
             o = torch.argsort(par.double() * 4.0 - sim.double())  # by parent, most similar child first
             par_s, child_s = par[o], chd[o]
             first = torch.ones_like(par_s, dtype=torch.bool)
@@ -537,7 +537,7 @@ def train_pq(x: torch.Tensor, m: int, K: int = 256, iters: int = 6, seed: int = 
     g = torch.Generator(device=x.device)
     g.manual_seed(seed)
     pick = torch.randperm(n, generator=g, device=x.device)[:min(sample, n)]
-    xs = x[pick]
+    xs = x[pick].float()  # (x may be bf16 rows)
     cb = torch.empty((m, K, dsub), dtype=torch.float32, device=x.device)
     codes = torch.empty((n, m), dtype=torch.int16, device=x.device)
     for j in range(m):
@@ -552,7 +552,7 @@ def train_pq(x: torch.Tensor, m: int, K: int = 256, iters: int = 6, seed: int = 
             cent = torch.where(cnt[:, None] > 0, sums / cnt[:, None].clamp_min(1.0), cent)
         cb[j] = cent
         for s in range(0, n, chunk):
-            blk = x[s:s + chunk, j * dsub:(j + 1) * dsub]
+            blk = x[s:s + chunk, j * dsub:(j + 1) * dsub].float()
             codes[s:s + chunk, j] = torch.cdist(blk, cent).argmin(1).to(torch.int16)
     return cb, codes
 
