@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--nq", type=int, default=1024)
     ap.add_argument("--ef", type=int, default=128)
+    ap.add_argument("--ef-list", type=str, default="",
+                    help="comma-separated ef values searched one after the other over the same set-up (one JSON "
+                         "line each), stopping at the first that reaches recall@10 >= 0.95")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--tokens", type=int, default=64)
     ap.add_argument("--cache-rows", type=int, default=1 << 20)
@@ -162,46 +165,51 @@ def main():
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
     log("graph and index ready, searching")
-    t0 = time.time()
-    if pq is not None:
-        ids, dist, cnt = idx.search_two_level_batch(qh, args.k, args.ef, args.two_level)
-    else:
-        ids, dist, cnt = idx.search_batch(qh, args.k, args.ef)
-    dt = time.time() - t0
-    st = idx.last_stats()
     tih = ti.cpu().numpy()
-    hit = sum(len(set(ids[i, :cnt[i]].tolist()) & set(tih[i].tolist())) for i in range(args.nq))
-    enc_tflops = st["encoded_nodes"] * flops_per_node / dt / 1e12
-    mode_label = "bf16 Linear layers, float32 accumulation" if args.bf16 else "float32 MFMA"
-    res = {
-        "metric": "queries/s, recompute provider (BASELINE config 3)",
-        "value": round(args.nq / dt, 2), "unit": "queries/s",
-        "config": {"workload": f"{N} nodes x {L} tokens, 6-layer encoder hidden 768 ({mode_label}), "
-                               f"query batch {args.nq}, k={args.k}, ef={args.ef}, cosine",
-                   "search": (f"two-level, rerank ratio {args.two_level}, PQ m={args.pq_m} K=256"
-                              if pq is not None else "LeannIndex::search"),
-                   "graph": gst},
-        "recall_at_10": round(hit / (args.nq * args.k), 4),
-        "seconds": round(dt, 2), "rounds": st["recompute_rounds"],
-        "evals": st["evals"], "approx_evals": st["pushes"] if pq is not None else 0,
-        "encoded_nodes": st["encoded_nodes"],
-        "search_kernel_ms_all_rounds": round(st["kernel_ms"], 1),
-        "provider_hbm_bytes": {"row_cache_and_slot_map": idx.recompute_cache_bytes(), "token_table": N * L * 2,
-                               "dense_table_would_be": N * h * 4},
-        "roofline": {"bound": "mfma", "achieved": round(enc_tflops, 1),
-                     "peak": 2500.0 if args.bf16 else MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(enc_tflops / (2500.0 if args.bf16 else MFMA_F32_PEAK_TFLOPS), 4),
-                     "note": "encoder flops of the call / wall time of the call (rounds, gathers and "
-                             "traversal included); layers*(24 h^2 L + 4 L^2 h) flops per node"},
-        "encode_all_nodes_seconds": round(t_all, 1),
-        "encode_all_tflops": round(N * flops_per_node / t_all / 1e12, 1),
-    }
-    if mem_res is not None:
-        res["equals_in_memory_provider"] = bool(
-            (mem_res[0] == ids).all() and (mem_res[1].view(np.uint32) == dist.view(np.uint32)).all()
-            and (mem_res[2] == cnt).all()
-            and all(mem_stats[f] == st[f] for f in ("expansions", "edges", "evals", "pushes")))
-    print(json.dumps(res))
+    efs = [int(e) for e in args.ef_list.split(",") if e] or [args.ef]
+    for ef in efs:
+        t0 = time.time()
+        if pq is not None:
+            ids, dist, cnt = idx.search_two_level_batch(qh, args.k, ef, args.two_level)
+        else:
+            ids, dist, cnt = idx.search_batch(qh, args.k, ef)
+        dt = time.time() - t0
+        st = idx.last_stats()
+        hit = sum(len(set(ids[i, :cnt[i]].tolist()) & set(tih[i].tolist())) for i in range(args.nq))
+        enc_tflops = st["encoded_nodes"] * flops_per_node / dt / 1e12
+        mode_label = "bf16 Linear layers, float32 accumulation" if args.bf16 else "float32 MFMA"
+        res = {
+            "metric": "queries/s, recompute provider (BASELINE config 3)",
+            "value": round(args.nq / dt, 2), "unit": "queries/s",
+            "config": {"workload": f"{N} nodes x {L} tokens, 6-layer encoder hidden 768 ({mode_label}), "
+                                   f"query batch {args.nq}, k={args.k}, ef={ef}, cosine",
+                       "search": (f"two-level, rerank ratio {args.two_level}, PQ m={args.pq_m} K=256"
+                                  if pq is not None else "LeannIndex::search"),
+                       "graph": gst},
+            "recall_at_10": round(hit / (args.nq * args.k), 4),
+            "seconds": round(dt, 2), "rounds": st["recompute_rounds"],
+            "evals": st["evals"], "approx_evals": st["pushes"] if pq is not None else 0,
+            "encoded_nodes": st["encoded_nodes"],
+            "search_kernel_ms_all_rounds": round(st["kernel_ms"], 1),
+            "provider_hbm_bytes": {"row_cache_and_slot_map": idx.recompute_cache_bytes(), "token_table": N * L * 2,
+                                   "dense_table_would_be": N * h * 4},
+            "roofline": {"bound": "mfma", "achieved": round(enc_tflops, 1),
+                         "peak": 2500.0 if args.bf16 else MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(enc_tflops / (2500.0 if args.bf16 else MFMA_F32_PEAK_TFLOPS), 4),
+                         "note": "encoder flops of the call / wall time of the call (rounds, gathers and "
+                                 "traversal included); layers*(24 h^2 L + 4 L^2 h) flops per node"},
+            "encode_all_nodes_seconds": round(t_all, 1),
+            "encode_all_tflops": round(N * flops_per_node / t_all / 1e12, 1),
+        }
+        if mem_res is not None and ef == args.ef:
+            res["equals_in_memory_provider"] = bool(
+                (mem_res[0] == ids).all() and (mem_res[1].view(np.uint32) == dist.view(np.uint32)).all()
+                and (mem_res[2] == cnt).all()
+                and all(mem_stats[f] == st[f] for f in ("expansions", "edges", "evals", "pushes")))
+        print(json.dumps(res), flush=True)
+        log(f"ef={ef}: recall {res['recall_at_10']}, {dt:.1f}s")
+        if res["recall_at_10"] >= 0.95:
+            break
 
 
 if __name__ == "__main__":
