@@ -209,7 +209,7 @@ def _knn_in_buckets(x, member_ids, bucket_off, k, mem_budget=1.5e9):
             rowmask = msk[:, r0:r1]
             p = pos[:, r0:r1][rowmask]
             nbr[p, :kk] = gid[rowmask]
-            sim_out[p, :kk] = sv[rowmask]
+            sim_out[p, :kk] = sv[rowmask].float()
         i = j
     return nbr, sim_out
 
@@ -233,6 +233,7 @@ def _knn_exact(x, ids, k, chunk=4096):
 def _medoids(x, ids, C, chunk=1 << 18):
     """For every centroid the most similar point among `ids` (global ids, duplicates removed)."""
     dev = x.device
+    chunk = max(1024, min(chunk, (1 << 29) // x.shape[1]))
     k = C.shape[0]
     best_s = torch.full((k,), -3.0, device=dev)
     best_i = torch.zeros(k, dtype=torch.int64, device=dev)
@@ -255,6 +256,7 @@ def _lloyd_centroids(x, n_cent, iters=3, seed=11, chunk=1 << 18, ids=None):
     if ids is not None:
         x = x[ids]
     n, d = x.shape
+    chunk = max(1024, min(chunk, (1 << 29) // d))
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     C = x[torch.randperm(n, generator=g, device=dev)[:n_cent]].float().clone()  # (x may be bf16 rows)
@@ -291,6 +293,7 @@ def _knn_subset(x, ids, k, centroids=None, assign_chunk=1 << 18, exact_limit=400
     if n <= exact_limit or centroids is None:
         return _knn_exact(x, ids, min(k, n - 1))
     C = centroids
+    assign_chunk = max(1024, min(assign_chunk, (1 << 29) // x.shape[1]))
     a1 = torch.empty(n, dtype=torch.int64, device=dev)
     a2 = torch.empty(n, dtype=torch.int64, device=dev)
     Ch = C.to(_ASSIGN_DTYPE)
@@ -333,6 +336,9 @@ def _diversify(x, ids, cand, m, chunk=8192):
     dev = x.device
     n, K = cand.shape
     out = torch.full((n, m), -1, dtype=torch.int64, device=dev)
+    # the gathered candidate rows [chunk, K, d] stay below 2^30 elements (d = 4096: a tensor past
+    # 2^31 elements took the GPU down with a memory access fault in the gather / batched GEMM)
+    chunk = max(64, min(chunk, (1 << 30) // (K * x.shape[1])))
     for s0 in range(0, n, chunk):
         c = cand[s0:s0 + chunk]
         valid = c >= 0
@@ -365,6 +371,7 @@ def _diversify(x, ids, cand, m, chunk=8192):
 def _nearest_parent(x, child_ids, parent_ids, npar=2, chunk=1 << 16):
     """Indices (into parent_ids) of the npar most similar parents of every child: [n, npar]."""
     P = x[parent_ids]
+    chunk = max(1024, min(chunk, (1 << 29) // x.shape[1]))
     npar = min(npar, parent_ids.numel())
     out = torch.empty((child_ids.numel(), npar), dtype=torch.int64, device=x.device)
     for s0 in range(0, child_ids.numel(), chunk):
@@ -407,7 +414,7 @@ def _build_graph(x: torch.Tensor, m0: int = 60, k0: int = 28, k_upper: int = 20,
     # medoids of a spherical k-means over the level below, so that every region of the data
     # owns a node at every scale (a purely random sample leaves ~1/e of the natural
     # clusters without a representative two levels up, and those become unreachable).
-    exact_limit = 400_000
+    exact_limit = min(400_000, (1 << 30) // x.shape[1])  # the gathered rows of an exact kNN stay below 2^30 elements
     all_ids = torch.arange(n, device=dev)
     perm = torch.randperm(n, generator=g, device=dev)
     cent = None
@@ -536,6 +543,7 @@ def train_pq(x: torch.Tensor, m: int, K: int = 256, iters: int = 6, seed: int = 
     dsub = d // m
     g = torch.Generator(device=x.device)
     g.manual_seed(seed)
+    sample = max(4096, min(sample, (1 << 29) // d))
     pick = torch.randperm(n, generator=g, device=x.device)[:min(sample, n)]
     xs = x[pick].float()  # (x may be bf16 rows)
     cb = torch.empty((m, K, dsub), dtype=torch.float32, device=x.device)
