@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--skip-two-level", action="store_true")
+    ap.add_argument("--graph-only", action="store_true", help="stop after the graph (harness check)")
     a = ap.parse_args()
     N, d, nq, k, ef = a.nodes, a.dim, a.nq, a.k, a.ef
     dev = torch.device("cuda:0")
@@ -81,7 +82,7 @@ def main():
         ev1.record()
         torch.cuda.synchronize()
         gemm_ms += ev0.elapsed_time(ev1)
-        dd, ii = torch.topk(out[:, :c], k, dim=1, largest=False)
+        dd, ii = torch.topk(out.view(-1)[:nq * c].view(nq, c), k, dim=1, largest=False)  # [nq][c], dense
         cat_d = torch.cat([best_d, dd], 1)
         cat_i = torch.cat([best_i, ii + o], 1)
         sel = torch.topk(cat_d, k, dim=1, largest=False).indices
@@ -94,10 +95,14 @@ def main():
 
     # ---- graph (harness) on the bf16 rows
     t0 = time.time()
-    off, nb, entry = synth.build_graph(x16, m0=60)
+    # (every harness GEMM in float32: the bf16 GEMMs torch picks for these shapes ended in a GPU memory
+    # access fault at d = 4096, at 1M and at 10M rows alike)
+    off, nb, entry = synth.build_graph(x16, m0=60, precise=True)
     torch.cuda.synchronize()
     gst = synth.graph_stats(off)
     log(f"graph in {time.time() - t0:.1f}s: {gst}")
+    if a.graph_only:
+        return
     idx = ia.LeannIndex.from_device_csr(off.data_ptr(), nb.data_ptr(), N, entry, d, ia.LeannConfig.paper_default(), device=0)
     del off, nb
     idx.set_embeddings_bf16(None, device_ptr=x16.view(torch.int16).data_ptr(), n=N, d=d)

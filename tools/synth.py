@@ -146,6 +146,16 @@ def recall_at_k(found_ids: torch.Tensor, found_cnt: torch.Tensor, truth_ids: tor
 
 
 # ------------------------------------------------------------------ graph builder
+def _trace(msg):
+    """SYNTH_TRACE=1: phase markers with a device synchronisation in front (which phase a GPU fault
+    belongs to)."""
+    import os
+    import sys
+    if os.environ.get("SYNTH_TRACE"):
+        torch.cuda.synchronize()
+        print(f"[synth] {msg}", file=sys.stderr, flush=True)
+
+
 # dtype of the k-means / bucket ASSIGNMENT GEMMs (build_graph(precise=True) switches to float32:
 # embeddings with a large common component -- a randomly initialised encoder's -- differ from each
 # other only past bfloat16's 8 bits)
@@ -196,7 +206,7 @@ def _knn_in_buckets(x, member_ids, bucket_off, k, mem_budget=1.5e9):
             pos[gi, : s1 - s0] = torch.arange(s0, s1, device=dev)
         kk = min(k, S - 1)
         rows_per = max(1, int(mem_budget // (G * S * 4)))
-        X = x[idx]  # [G, S, d]
+        X = x[idx].float()  # [G, S, d] (float32 whatever the rows' storage type)
         for r0 in range(0, S, rows_per):
             r1 = min(S, r0 + rows_per)
             sim = torch.bmm(X[:, r0:r1], X.transpose(1, 2))  # [G, r, S]
@@ -209,7 +219,7 @@ def _knn_in_buckets(x, member_ids, bucket_off, k, mem_budget=1.5e9):
             rowmask = msk[:, r0:r1]
             p = pos[:, r0:r1][rowmask]
             nbr[p, :kk] = gid[rowmask]
-            sim_out[p, :kk] = sv[rowmask].float()
+            sim_out[p, :kk] = sv[rowmask]
         i = j
     return nbr, sim_out
 
@@ -219,7 +229,7 @@ def _knn_exact(x, ids, k, chunk=4096):
     """Exact cosine kNN among the points `ids` (rows L2-normalised), row-chunked GEMM + top-k.
     Returns int64 [len(ids), k] GLOBAL ids sorted by decreasing similarity."""
     n = ids.numel()
-    X = x[ids]
+    X = x[ids].float()
     out = torch.empty((n, k), dtype=torch.int64, device=x.device)
     for s0 in range(0, n, chunk):
         sim = X[s0:s0 + chunk] @ X.T
@@ -338,12 +348,12 @@ def _diversify(x, ids, cand, m, chunk=8192):
     out = torch.full((n, m), -1, dtype=torch.int64, device=dev)
     # the gathered candidate rows [chunk, K, d] stay below 2^30 elements (d = 4096: a tensor past
     # 2^31 elements took the GPU down with a memory access fault in the gather / batched GEMM)
-    chunk = max(64, min(chunk, (1 << 30) // (K * x.shape[1])))
+    chunk = max(64, min(chunk, (1 << 29) // (K * x.shape[1])))
     for s0 in range(0, n, chunk):
         c = cand[s0:s0 + chunk]
         valid = c >= 0
-        B = x[ids[s0:s0 + chunk]]
-        Cv = x[c.clamp_min(0)]
+        B = x[ids[s0:s0 + chunk]].float()
+        Cv = x[c.clamp_min(0)].float()
         sb = torch.bmm(Cv, B[:, :, None]).squeeze(2)          # similarity candidate <-> base
         pair = torch.bmm(Cv, Cv.transpose(1, 2))               # candidate <-> candidate
         sel = torch.zeros_like(valid)
@@ -370,12 +380,12 @@ def _diversify(x, ids, cand, m, chunk=8192):
 @torch.no_grad()
 def _nearest_parent(x, child_ids, parent_ids, npar=2, chunk=1 << 16):
     """Indices (into parent_ids) of the npar most similar parents of every child: [n, npar]."""
-    P = x[parent_ids]
+    P = x[parent_ids].float()
     chunk = max(1024, min(chunk, (1 << 29) // x.shape[1]))
     npar = min(npar, parent_ids.numel())
     out = torch.empty((child_ids.numel(), npar), dtype=torch.int64, device=x.device)
     for s0 in range(0, child_ids.numel(), chunk):
-        out[s0:s0 + chunk] = torch.topk((x[child_ids[s0:s0 + chunk]] @ P.T).float(), npar, dim=1).indices
+        out[s0:s0 + chunk] = torch.topk(x[child_ids[s0:s0 + chunk]].float() @ P.T, npar, dim=1).indices
     return out
 
 
@@ -414,7 +424,7 @@ def _build_graph(x: torch.Tensor, m0: int = 60, k0: int = 28, k_upper: int = 20,
     # medoids of a spherical k-means over the level below, so that every region of the data
     # owns a node at every scale (a purely random sample leaves ~1/e of the natural
     # clusters without a representative two levels up, and those become unreachable).
-    exact_limit = min(400_000, (1 << 30) // x.shape[1])  # the gathered rows of an exact kNN stay below 2^30 elements
+    exact_limit = min(400_000, (1 << 29) // x.shape[1] * 2)  # the gathered rows of an exact kNN stay below 2^30 elements
     all_ids = torch.arange(n, device=dev)
     perm = torch.randperm(n, generator=g, device=dev)
     cent = None
@@ -424,7 +434,9 @@ def _build_graph(x: torch.Tensor, m0: int = 60, k0: int = 28, k_upper: int = 20,
         n2 = max(1, n1 // level_ratio)
         uppers = []
         if n2 > k_upper // 2:
+            _trace(f"lloyd {n2} centroids")
             cent = _lloyd_centroids(x, n2)
+            _trace("medoids")
             cur = _medoids(x, all_ids, cent)
             uppers.append(cur)
             while cur.numel() > k_upper:
@@ -453,6 +465,7 @@ def _build_graph(x: torch.Tensor, m0: int = 60, k0: int = 28, k_upper: int = 20,
     for li, ids in enumerate(levels):
         if ids.numel() < 2:
             continue
+        _trace(f"level {li}: {ids.numel()} nodes")
         use_cent = cent
         if li == 0:
             nb = _knn_subset(x, ids, min(k0, ids.numel() - 1), use_cent, exact_limit=exact_limit)
@@ -499,11 +512,13 @@ def _build_graph(x: torch.Tensor, m0: int = 60, k0: int = 28, k_upper: int = 20,
             okc = within < cpool
             cand = torch.full((parents.numel(), cpool), -1, dtype=torch.int64, device=dev)
             cand[par_s[okc], within[okc]] = child_s[okc]
+            _trace(f"level {li}: children of {parents.numel()} parents")
             ch = _diversify(x, parents, cand, child_cap)
             psrc = parents[:, None].expand_as(ch).reshape(-1)
             prank = torch.arange(ch.shape[1], device=dev)[None, :].expand_as(ch).reshape(-1)
             add_edges(psrc, ch.reshape(-1), prank)
             ids = ids_saved
+    _trace("edges collected")
     src, dst, prio = torch.cat(E_src), torch.cat(E_dst), torch.cat(E_prio)
     # reverse edges rank behind every forward edge
     src, dst, prio = torch.cat([src, dst]), torch.cat([dst, src]), torch.cat([prio, prio + 1000])
