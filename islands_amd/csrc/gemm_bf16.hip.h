@@ -166,10 +166,7 @@ typedef const __attribute__((address_space(1))) void isl_glb_void;
 //   <2,2,2,2>: 128 x 128, 256 threads, 64 KiB LDS, two workgroups per CU;
 //   <2,4,4,2>: 256 x 256, 512 threads, 128 KiB LDS, one per CU -- 128 x 64 per wave reads 6 operand
 //   fragments per 8 MFMAs instead of 4 per 4, and a slab byte feeds twice the flops.
-// SPREAD: the DMA instructions of the next slab are issued between the k-steps of the current one
-// (a quarter each) instead of in one burst behind the barrier, where both waves of a SIMD would issue
-// them in lock-step while its matrix pipe idles.
-template <int ACT, bool RES, bool C16, int WM, int WN, int MF, int NF, bool SPREAD = false>
+template <int ACT, bool RES, bool C16, int WM, int WN, int MF, int NF>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_bf16_dma(const __bf16* __restrict__ A,
                                                                  const __bf16* __restrict__ W,
                                                                  const float* __restrict__ bias,
@@ -234,24 +231,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_bf16_dma(const __bf16* _
   for (uint32_t kt = 0; kt < nk; ++kt) {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of slab kt has landed
     __syncthreads();  // everyone's share has; everyone is done reading the other buffer
-    if (!SPREAD && kt + 1 < nk) issue((kt + 1) * HBK, (kt + 1) & 1);
+    if (kt + 1 < nk) issue((kt + 1) * HBK, (kt + 1) & 1);
     const unsigned char* ab = lds + (kt & 1) * BUF;
     const unsigned char* wb = ab + ABYTES;
 #pragma unroll
     for (int ks = 0; ks < HBK / 16; ++ks) {
-      if constexpr (SPREAD) {
-        if (kt + 1 < nk) {
-          unsigned char* nab = lds + ((kt + 1) & 1) * BUF;
-          unsigned char* nwb = nab + ABYTES;
-          const uint32_t nk0 = (kt + 1) * HBK;
-#pragma unroll
-          for (int i = ks * NIA / 4; i < (ks + 1) * NIA / 4; ++i)
-            __builtin_amdgcn_global_load_lds((isl_glb_void*)(asrc[i] + nk0), (isl_lds_void*)(nab + (NW * i + wave) * 1024u), 16, 0, 0);
-#pragma unroll
-          for (int i = ks * NIW / 4; i < (ks + 1) * NIW / 4; ++i)
-            __builtin_amdgcn_global_load_lds((isl_glb_void*)(wsrc[i] + nk0), (isl_lds_void*)(nwb + (NW * i + wave) * 1024u), 16, 0, 0);
-        }
-      }
       const uint32_t cl = 2 * ks + kh;  // logical 16-byte chunk of the row
       bf16x8 b[NF];
 #pragma unroll
@@ -307,18 +291,7 @@ void launch_gemm_bf16_dma(const __bf16* A, const __bf16* W, const float* bias, c
   static const int tile_env = [] { const char* e = getenv("ISL_GEMM_TILE"); return e ? atoi(e) : 0; }();  // 128 / 256: A/B switch
   const uint64_t big = ((M + 255) / 256) * ((N + 255) / 256);
   const bool use_big = tile_env == 256 || (tile_env != 128 && big >= 512);
-  static const bool spread = getenv("ISL_GEMM_SPREAD") != nullptr;  // A/B switch for measurements
-  if (use_big && spread) {
-    auto kern = gemm_tn_bf16_dma<ACT, RES, C16, 2, 4, 4, 2, true>;
-    constexpr size_t lds = 2 * (256 + 256) * HBK * 2;
-    static const bool once = [&] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      return true;
-    }();
-    (void)once;
-    hipLaunchKernelGGL(kern, dim3((uint32_t)big), dim3(512), lds, st, A, W, bias, R, C, (uint32_t)M, (uint32_t)N,
-                       (uint32_t)K, (uint32_t)((N + 255) / 256), ldc);
-  } else if (use_big) {
+  if (use_big) {
     auto kern = gemm_tn_bf16_dma<ACT, RES, C16, 2, 4, 4, 2>;
     constexpr size_t lds = 2 * (256 + 256) * HBK * 2;
     static const bool once = [&] {
