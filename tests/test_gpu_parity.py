@@ -332,6 +332,53 @@ def test_merge_topk_matches_multi_index_searcher(orc):  # search.rs:211-237
         assert osrc[q, :n].tolist() == esrc.tolist() and bits(osc[q, :n]).tolist() == bits(es).tolist()
 
 
+def test_merge_topk_packed_records_equal_the_dense_merge(orc):
+    """The multi-GPU exchange form of the same merge (search.rs:211-237): every shard's answers as
+    one packed record (ids | distances | counts, isl_shard_record_bytes), records a stride apart as
+    an all-gather leaves them, merged by isl_merge_topk_packed_async with no host wait."""
+    import ctypes as C
+
+    import torch
+
+    from islands_amd import _ffi
+    from islands_amd.sharded import record_bytes, record_views
+
+    rng = np.random.default_rng(8)
+    for (nl, nq, k, top) in ((3, 17, 6, 6), (8, 5, 10, 10), (2, 33, 1, 1)):
+        scores = np.sort(rng.integers(0, 8, (nl, nq, k)).astype(np.float32) / 4, axis=2)
+        ids = rng.integers(0, 1000, (nl, nq, k)).astype(np.uint64)
+        counts = rng.integers(0, k + 1, (nl, nq)).astype(np.uint32)
+        base = (np.arange(nl) * 1000).astype(np.uint64)
+        B = record_bytes(nq, k)
+        assert B == _ffi.lib().isl_shard_record_bytes(nq, k) and B % 16 == 0
+        gathered = torch.zeros((nl, B), dtype=torch.uint8)
+        g_ids, g_dd, g_cnt = record_views(gathered, nq, k)
+        g_ids.copy_(torch.from_numpy(ids.astype(np.int64)))
+        g_dd.copy_(torch.from_numpy(scores))
+        g_cnt.copy_(torch.from_numpy(counts.astype(np.int32)))
+        dg = gathered.cuda()
+        o_ids = torch.zeros((nq, top), dtype=torch.int64, device="cuda")
+        o_sc = torch.zeros((nq, top), dtype=torch.float32, device="cuda")
+        o_src = torch.zeros((nq, top), dtype=torch.int32, device="cuda")
+        o_cnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
+        flags = torch.zeros(1, dtype=torch.int32, device="cuda")
+        d_base = torch.from_numpy(base.astype(np.int64)).cuda()
+        torch.cuda.synchronize()
+        ia._check(_ffi.lib().isl_merge_topk_packed_async(
+            nl, nq, k, C.c_void_p(dg.data_ptr()), B, C.c_void_p(d_base.data_ptr()), top, C.c_void_p(o_ids.data_ptr()),
+            C.c_void_p(o_sc.data_ptr()), C.c_void_p(o_src.data_ptr()), C.c_void_p(o_cnt.data_ptr()),
+            C.c_void_p(flags.data_ptr()), 0, None))
+        torch.cuda.synchronize()
+        assert int(flags.item()) == 0
+        wi, ws, wsrc, wc = ia.merge_topk(ids, scores, counts, top, id_base=base)
+        assert o_cnt.cpu().numpy().astype(np.uint32).tolist() == wc.tolist()
+        for q in range(nq):
+            n = int(wc[q])
+            assert o_ids[q, :n].cpu().numpy().astype(np.uint64).tolist() == wi[q, :n].tolist()
+            assert bits(o_sc[q, :n].cpu().numpy()).tolist() == bits(ws[q, :n]).tolist()
+            assert o_src[q, :n].cpu().numpy().tolist() == wsrc[q, :n].tolist()
+
+
 # --------------------------------------------------------------------- pq.rs
 def test_pq_matches_oracle(orc):  # pq.rs:639-677, 787-809, 505-520
     rng = np.random.default_rng(4)
