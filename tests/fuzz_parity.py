@@ -202,16 +202,83 @@ def two_level_case(rng, case):
     return {"exact_path": 0, "replayed": 0}
 
 
+_RC = {}
+
+
+def recompute_case(rng, case):
+    """Recompute provider (leann.rs:82-99: embeddings computed on the fly) against the in-memory
+    provider holding the same embeddings: ids, distance bits, counts and work counters must be equal
+    whatever the row cache holds -- random cache sizes (down to the 256-row floor, so that rows are
+    evicted and re-encoded inside a call and the batch runs a few queries at a time), rows past 64
+    ids, quantised token rows (equal embeddings -> ties -> heap-exact kernel, which re-runs blocked
+    queries from their start), keep_rows on and off, every metric and result-set size."""
+    import bert_ref
+    if "enc" not in _RC:
+        cfg = dict(vocab_size=200, hidden=32, layers=1, heads=2, intermediate=64, max_position=16, type_vocab=2)
+        w = bert_ref.random_weights(cfg, seed=45, std=0.3)
+        _RC["cfg"] = cfg
+        _RC["enc"] = ia.CandleEmbedder(ia.BertConfig(**{k: cfg[k] for k in cfg}), w, normalize=True)
+    enc = _RC["enc"]
+    n = int(rng.choice([300, 800, 1500]))
+    L = int(rng.choice([6, 12]))
+    seed = int(rng.integers(1 << 30))
+    r2 = np.random.default_rng(seed)
+    ties = rng.random() < 0.2
+    tok = r2.integers(1, 200, (n, L)).astype(np.uint16)
+    topics = r2.integers(1, 200, (12, L // 2))
+    tok[:, :L // 2] = topics[r2.integers(0, 12, n)]
+    lens = None
+    if ties:  # a quarter of the rows are copies: equal embeddings, equal distances
+        tok[n // 2: n // 2 + n // 4] = tok[:n // 4]
+    elif rng.random() < 0.5:
+        lens = r2.integers(L // 2 + 1, L + 1, n).astype(np.uint16)
+    mask = None if lens is None else (np.arange(L)[None, :] < lens[:, None]).astype(np.float32)
+    emb = np.concatenate([enc.embed(tok[o:o + 512].astype(np.int64), None, None if mask is None else mask[o:o + 512])
+                          for o in range(0, n, 512)])
+    deg = int(rng.choice([8, 30, 64, 100]))
+    off, nb = random_csr(n, min(deg, n - 1), seed)
+    metric = int(rng.integers(0, 4))
+    ef = int(rng.choice([4, 33, 64, 128, 200, 300]))
+    k = int(rng.choice([1, 5, 10]))
+    cfg = ia.LeannConfig(m=max(2, deg // 2), m0=max(deg, 4), ef_construction=max(deg, 128) if deg <= 128 else 200,
+                         metric=ia.DistanceMetric(metric))
+    entry = int(rng.integers(0, n))
+    g = ia.CsrGraph(node_offsets=off, neighbors=nb, levels=np.zeros(n, np.uint64), entry_point=entry, num_nodes=n,
+                    degree_counts=(off[1:] - off[:-1]).astype(np.uint64))
+    nq = int(rng.choice([1, 7, 40]))
+    q = (emb[r2.integers(0, n, nq)] + r2.standard_normal((nq, emb.shape[1])).astype(np.float32) * np.float32(0.05))
+    mem = ia.LeannIndex.from_csr(g, cfg, dimension=emb.shape[1]).upload(0)
+    mem.set_embeddings(emb)
+    want = mem.search_batch(q, k, ef)
+    ws = mem.last_stats()
+    # equal embeddings send queries to the heap-exact kernel, which needs its traversal resident
+    rows = n if ties else int(rng.choice([256, max(256, n // 3), n]))
+    keep = bool(rng.random() < 0.3)
+    rec = ia.LeannIndex.from_csr(g, cfg, dimension=emb.shape[1]).upload(0)
+    rec.set_recompute_provider(enc, tok, lens, keep_rows=keep, cache_rows=rows)
+    desc = f"case {case}: n={n} L={L} deg={deg} metric={metric} ef={ef} k={k} nq={nq} rows={rows} keep={keep} ties={ties}"
+    for rep in range(2):
+        got = rec.search_batch(q, k, ef)
+        st = rec.last_stats()
+        assert got[2].tolist() == want[2].tolist(), desc
+        assert got[0].tolist() == want[0].tolist(), desc
+        assert bits(got[1]).tolist() == bits(want[1]).tolist(), desc
+        for f in ("expansions", "edges", "evals", "pushes"):
+            assert st[f] == ws[f], (desc, f, st[f], ws[f])
+    return {"exact_path": ws["exact_path"], "replayed": ws["replayed"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--mode", choices=["leann", "hnsw", "build", "two_level"], default="leann")
+    ap.add_argument("--mode", choices=["leann", "hnsw", "build", "two_level", "recompute"], default="leann")
     args = ap.parse_args()
     orc.build()
     rng = np.random.default_rng(args.seed)
     t0, case, exact, replay = time.time(), 0, 0, 0
-    fn = {"leann": one_case, "hnsw": hnsw_case, "build": build_case, "two_level": two_level_case}[args.mode]
+    fn = {"leann": one_case, "hnsw": hnsw_case, "build": build_case, "two_level": two_level_case,
+          "recompute": recompute_case}[args.mode]
     while time.time() - t0 < args.seconds:
         st = fn(rng, case)
         exact += st["exact_path"]

@@ -193,6 +193,15 @@ def test_recompute_provider_small_row_cache(orc):
         assert st["encoded_nodes"] <= min(want_stats["evals"], n)  # each node once per call
 
 
+def test_recompute_fuzz_slice(orc):
+    """A fixed slice of tests/fuzz_parity.py --mode recompute (random graphs incl. rows past 64 ids,
+    metrics, ef, cache sizes down to the 256-row floor, tied embeddings, keep_rows)."""
+    import fuzz_parity
+    rng = np.random.default_rng(2024)
+    for case in range(10):
+        fuzz_parity.recompute_case(rng, case)
+
+
 def test_recompute_provider_keeps_rows_when_asked(orc):
     cfg, enc, tok, lens, emb = _recompute_case(orc, n=400, seed=9)
     levels = np.zeros(400, np.uint64)
