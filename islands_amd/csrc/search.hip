@@ -555,8 +555,12 @@ void note_last_stats(const isl_index* idx, const isl_search_stats& st) {
 
 // Waits for the call in flight on `ws`, leaves its counters in ws.stats and turns per-query
 // failures into the CoreError the reference's sequential map would have returned.
+isl_status search_statuses(isl::SearchWorkspace& ws, uint64_t nq, bool* window_short);
+
+// defer_statuses: the per-query statuses are not final yet (a batch the recompute provider works
+// through in rounds, some of its queries not even started): the caller runs search_statuses itself.
 isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws, uint32_t* misses = nullptr,
-                         bool* window_short = nullptr) {
+                         bool* window_short = nullptr, bool defer_statuses = false) {
   if (!ws.enqueued) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "no search in flight for this token");
   ws.enqueued = false;
   const uint64_t nq = ws.nq_inflight;
@@ -623,6 +627,13 @@ isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws, uint32_
     *misses = head[13];
     if (head[13]) return ISL_OK;  // a round of the recompute provider: statuses are not final yet
   }
+  if (defer_statuses) return ISL_OK;
+  return search_statuses(ws, nq, window_short);
+}
+
+// per-query failures -> the CoreError the reference's sequential map would have returned
+isl_status search_statuses(isl::SearchWorkspace& ws, uint64_t nq, bool* window_short) {
+  const uint32_t* status = ws.h_status;
   for (uint64_t i = 0; i < nq; i++) {  // first failing query wins, like the sequential map
     if (status[i] == QS_OK) continue;
     if (status[i] == QS_NODE_NOT_FOUND) {
@@ -820,7 +831,7 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
     ISL_TRY(search_enqueue(idx, ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, user_stream, mode, tl));
     uint32_t misses = 0;
     bool window_short = false;
-    const isl_status fst = search_finish(idx, ws, &misses, tl ? &window_short : nullptr);
+    const isl_status fst = search_finish(idx, ws, &misses, tl ? &window_short : nullptr, resumable);
     if (fst == ISL_ERR_SEARCH && window_short && tcall.window_scale < 64) { tcall.window_scale *= 4; continue; }
     ISL_TRY(fst);
     kernel_ms += ws.stats.kernel_ms;
@@ -832,7 +843,10 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
       while (na < max_active && next_fresh < nq) ws.h_qlist[na++] = next_fresh++;
       active = na;
       listed = true;
-      if (!active) break;
+      if (!active) {  // every query has run to its end: now the statuses are final
+        ISL_TRY(search_statuses(ws, nq, nullptr));
+        break;
+      }
       hipLaunchKernelGGL(copy_u32_kernel, dim3(16), dim3(256), 0, st, ws.h_qlist, ws.qlist, (uint64_t)na);
     } else if (!misses) {
       break;
