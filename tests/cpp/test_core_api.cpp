@@ -94,6 +94,31 @@ static void test_gpu() {
   EXPECT(res.size() == 5 && res[0].first == 0 && res[0].second < 0.01f);
   for (size_t i = 1; i < res.size(); i++) EXPECT(res[i - 1].second <= res[i].second);  // :1327-1343
   EXPECT(throws(ISL_ERR_DIMENSION_MISMATCH, [&] { idx.search(std::vector<float>(8, 0.5f), 5); }));  // :1315-1325
+  // pipelined host-buffer calls through the raw ABI: after isl_index_prepare no call allocates, every
+  // token carries its own statistics, and the answers equal the synchronous call's
+  {
+    idx.prepare(4, 200, 5, 3);
+    std::vector<float> qs;
+    for (size_t b = 0; b < 4; ++b) qs.insert(qs.end(), vecs.begin() + b * 7 * d, vecs.begin() + (b * 7 + 1) * d);  // rows 0, 7, 14, 21
+    uint64_t tok[3];
+    std::vector<uint64_t> ids[3];
+    std::vector<float> dist[3];
+    std::vector<uint32_t> cnt[3];
+    for (int c = 0; c < 3; ++c) {
+      const uint64_t nqc = (uint64_t)c + 2;  // 2, 3, 4 queries
+      ids[c].assign(nqc * 5, 0); dist[c].assign(nqc * 5, 0.f); cnt[c].assign(nqc, 0);
+      check(isl_search_batch_async(idx.handle(), qs.data(), nqc, d, 5, 200, ids[c].data(), dist[c].data(),
+                                   cnt[c].data(), &tok[c]));
+    }
+    for (int c = 2; c >= 0; --c) {
+      isl_search_stats st{};
+      check(isl_search_wait_stats(idx.handle(), tok[c], &st));
+      EXPECT(st.queries == (uint64_t)c + 2 && st.allocations == 0);
+      EXPECT(cnt[c][0] == 5 && ids[c][0] == 0 && dist[c][0] < 0.01f);
+      EXPECT(ids[c][5] == 7);  // the second query is row 7
+    }
+    EXPECT(isl_search_wait(idx.handle(), tok[0]) == ISL_ERR_INVALID_ARGUMENT);  // a token completes once
+  }
   LeannIndex empty = LeannIndex::with_defaults();  // :1306-1313
   EXPECT(empty.search(std::vector<float>(8, 0.5f), 5).empty());
 
