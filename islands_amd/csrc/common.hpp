@@ -61,6 +61,7 @@ struct SearchWorkspace {
   uint32_t* ticket = nullptr;  // work-queue heads (fast, exact)
   uint32_t* redo = nullptr;    // [cap_q] query ids routed to the exact kernel
   uint32_t* replay = nullptr;  // [cap_q] query ids routed to the replay kernel
+  uint32_t* qsel = nullptr;    // [cap_q] bf16 rows: queries whose elements are not all bf16 values
   uint64_t* plog = nullptr;    // [cap_q][plog_cap] push log (distance bits, id)
   uint64_t plog_entries = 0;
   // staging for the host-pointer entry points: device side ...

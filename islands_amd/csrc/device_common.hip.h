@@ -434,8 +434,47 @@ __device__ __forceinline__ float direct_group(const float* __restrict__ emb, uin
 // exactly representable in f32 and widened before use: the arithmetic is the f32 chain of the
 // reference run on the widened rows.
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+// The query operand of one step (8 elements per lane) as it waits in registers.  QH = the query
+// sits in LDS as bf16 bit patterns (every element of it is a bf16 value: checked where it is
+// loaded), half the LDS per wave -- at d = 4096 that is what bounds the waves per CU; the values
+// are widened exactly like the row's.
+template <bool QH> struct QStep;
+template <> struct QStep<false> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const float* qs, uint32_t e) {
+    a = *reinterpret_cast<const float4*>(qs + e);
+    b = *reinterpret_cast<const float4*>(qs + e + 4u);
+  }
+  __device__ __forceinline__ void load_guarded(const float* qs, uint32_t e, uint32_t d) {
+    const uint32_t dq = (d + 3u) & ~3u;
+    a = make_float4(0.f, 0.f, 0.f, 0.f);
+    b = a;
+    if (e < dq) a = *reinterpret_cast<const float4*>(qs + e);
+    if (e + 4u < dq) b = *reinterpret_cast<const float4*>(qs + e + 4u);
+  }
+  __device__ __forceinline__ float4 lo() const { return a; }
+  __device__ __forceinline__ float4 hi() const { return b; }
+};
+template <> struct QStep<true> {
+  v4u w;
+  __device__ __forceinline__ void load(const float* qs, uint32_t e) {
+    w = *reinterpret_cast<const v4u*>(reinterpret_cast<const uint16_t*>(qs) + e);
+  }
+  __device__ __forceinline__ void load_guarded(const float* qs, uint32_t e, uint32_t d) {
+    w = v4u{0u, 0u, 0u, 0u};
+    if (e < ((d + 7u) & ~7u)) w = *reinterpret_cast<const v4u*>(reinterpret_cast<const uint16_t*>(qs) + e);
+  }
+  __device__ __forceinline__ float4 lo() const {
+    return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xFFFF0000u),
+                       __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xFFFF0000u));
+  }
+  __device__ __forceinline__ float4 hi() const {
+    return make_float4(__uint_as_float(w.z << 16), __uint_as_float(w.z & 0xFFFF0000u),
+                       __uint_as_float(w.w << 16), __uint_as_float(w.w & 0xFFFF0000u));
+  }
+};
 #define ISL_RING(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11)
-template <int METRIC>
+template <int METRIC, bool QH = false>
 __device__ __forceinline__ float direct_group_bf16(const uint16_t* __restrict__ emb, uint64_t stride,
                                                    uint32_t d, uint32_t rid, uint32_t g0, uint32_t Rg,
                                                    const float* qs, float q_norm, float row_aux) {
@@ -446,7 +485,6 @@ __device__ __forceinline__ float direct_group_bf16(const uint16_t* __restrict__ 
   float a0 = 0.0f, a1 = 0.0f;
   if (r < Rg) {
     const uint16_t* rp = emb + (uint64_t)row * stride + s8;
-    const float* qp = qs + s8;
     const uint32_t nF = d >> 5;
     const uint32_t nS = (d + 31u) >> 5;
 #define ISL_ADD(ss, c)                                                           \
@@ -476,14 +514,13 @@ __device__ __forceinline__ float direct_group_bf16(const uint16_t* __restrict__ 
 #define ISL_QNEXT(k)                                                              \
     {                                                                             \
       const uint32_t sn_ = base + (k) + 1u < nS ? base + (k) + 1u : nS - 1u;      \
-      qna = *reinterpret_cast<const float4*>(qp + 32u * sn_);                     \
-      qnb = *reinterpret_cast<const float4*>(qp + 32u * sn_ + 4u);                \
+      qn.load(qs, s8 + 32u * sn_);                                                \
     }
 #define ISL_ALL_ADDS ISL_OCT(ISL_ADD, 0) ISL_OCT(ISL_ADD, 1) ISL_OCT(ISL_ADD, 2) ISL_OCT(ISL_ADD, 3)
 #define ISL_STEP_RELOAD(k)                                                        \
   {                                                                               \
     ISL_TAKE(k)                                                                   \
-    const float4 qa = qna, qb = qnb;                                              \
+    const float4 qa = qn.lo(), qb = qn.hi();                                      \
     ISL_WIDEN                                                                     \
     ISL_TERMS                                                                     \
     ISL_PIN                                                                       \
@@ -495,7 +532,7 @@ __device__ __forceinline__ float direct_group_bf16(const uint16_t* __restrict__ 
 #define ISL_STEP(k)                                                               \
   {                                                                               \
     ISL_TAKE(k)                                                                   \
-    const float4 qa = qna, qb = qnb;                                              \
+    const float4 qa = qn.lo(), qb = qn.hi();                                      \
     ISL_WIDEN                                                                     \
     ISL_TERMS                                                                     \
     ISL_PIN                                                                       \
@@ -507,7 +544,8 @@ __device__ __forceinline__ float direct_group_bf16(const uint16_t* __restrict__ 
     uint32_t base = 0;
     if (nF >= (uint32_t)RING) {
       ISL_RING(ISL_ISSUE)
-      float4 qna = *reinterpret_cast<const float4*>(qp), qnb = *reinterpret_cast<const float4*>(qp + 4);
+      QStep<QH> qn;
+      qn.load(qs, s8);
       ISL_PIN
       while (base + 2u * RING <= nF) {
         ISL_RING(ISL_STEP_RELOAD)
@@ -528,10 +566,9 @@ __device__ __forceinline__ float direct_group_bf16(const uint16_t* __restrict__ 
   if ((uint32_t)(k) < rem) {                                                        \
     const uint32_t e0 = 32u * (base + (k));                                         \
     ISL_TAKE(k)                                                                     \
-    float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;                           \
-    const uint32_t dq_ = (d + 3u) & ~3u;                                            \
-    if (e0 + s8 < dq_) qa = *reinterpret_cast<const float4*>(qp + e0);              \
-    if (e0 + s8 + 4u < dq_) qb = *reinterpret_cast<const float4*>(qp + e0 + 4u);    \
+    QStep<QH> qg_;                                                                  \
+    qg_.load_guarded(qs, e0 + s8, d);                                               \
+    const float4 qa = qg_.lo(), qb = qg_.hi();                                      \
     ISL_WIDEN                                                                       \
     ISL_TERMS                                                                       \
     ISL_OCT(ISL_ADD_G, 0) ISL_OCT(ISL_ADD_G, 1) ISL_OCT(ISL_ADD_G, 2) ISL_OCT(ISL_ADD_G, 3) \
@@ -562,7 +599,7 @@ __device__ __forceinline__ float direct_group_bf16(const uint16_t* __restrict__ 
 
 // Tile-free counterpart of wave_distances: lane j < R receives the distance of row rid(j).
 // ROWT = float or uint16_t (bf16 bits).
-template <int METRIC, typename ROWT = float>
+template <int METRIC, typename ROWT = float, bool QH = false>
 __device__ __forceinline__ float direct_distances(const ROWT* __restrict__ emb, uint64_t stride,
                                                   uint32_t d, uint32_t rid, uint32_t R,
                                                   const float* qs, float q_norm, float row_aux = 0.0f) {
@@ -572,7 +609,7 @@ __device__ __forceinline__ float direct_distances(const ROWT* __restrict__ emb, 
     const uint32_t Rg = R - g0 < (uint32_t)GROUP ? R - g0 : (uint32_t)GROUP;
     float dist;
     if constexpr (sizeof(ROWT) == 2)
-      dist = direct_group_bf16<METRIC>(reinterpret_cast<const uint16_t*>(emb), stride, d, rid, g0, Rg, qs, q_norm, row_aux);
+      dist = direct_group_bf16<METRIC, QH>(reinterpret_cast<const uint16_t*>(emb), stride, d, rid, g0, Rg, qs, q_norm, row_aux);
     else
       dist = direct_group<METRIC>(reinterpret_cast<const float*>(emb), stride, d, rid, g0, Rg, qs, q_norm, row_aux);
     float moved = __shfl(dist, (4 * (lane - (int)g0)) & 63);
@@ -605,6 +642,31 @@ __device__ __forceinline__ float load_query(const float* __restrict__ q, uint32_
   if (METRIC == ISL_METRIC_COSINE || METRIC == METRIC_COSINE_PRE) {
     for (uint32_t j = 0; j < d; ++j) {
       float x = qs[j];
+      na += x * x;
+    }
+  }
+  return na;
+}
+
+// The same with the query kept in LDS as bf16 bit patterns (QStep<true>): *representable = false
+// when an element is not a bf16 value (the caller then answers the query with the f32-query kernel).
+template <int METRIC>
+__device__ __forceinline__ float load_query_bf16(const float* __restrict__ q, uint32_t d, float* qs,
+                                                 bool* representable) {
+  uint16_t* qh = reinterpret_cast<uint16_t*>(qs);
+  bool bad = false;
+  const uint32_t d8 = (d + 7u) & ~7u;
+  for (uint32_t j = threadIdx.x; j < d8; j += 64) {
+    const uint32_t u = j < d ? __float_as_uint(q[j]) : 0u;
+    bad |= (u & 0xFFFFu) != 0u;
+    qh[j] = (uint16_t)(u >> 16);
+  }
+  __syncthreads();
+  *representable = !ballot(bad);
+  float na = 0.0f;
+  if (METRIC == ISL_METRIC_COSINE || METRIC == METRIC_COSINE_PRE) {
+    for (uint32_t j = 0; j < d; ++j) {
+      float x = __uint_as_float((uint32_t)qh[j] << 16);
       na += x * x;
     }
   }

@@ -31,15 +31,17 @@ struct FastGeom {
   size_t lds;
 };
 
-FastGeom fast_geometry(uint32_t ef, uint32_t d) {
+// qbytes = bytes per query element in LDS: 4, or 2 for the instantiation that keeps a bf16-valued
+// query as bf16 (bf16 rows; at d = 4096 the query is what bounds the waves per CU)
+FastGeom fast_geometry(uint32_t ef, uint32_t d, uint32_t qbytes = 4) {
   // visited capacity grows with ef (V is roughly 10-30 x ef); overflow goes to HBM
   uint32_t hbits = ef <= 64 ? 10 : ef <= 160 ? 11 : ef <= 320 ? 12 : 13;
   static const int hbits_env = [] { const char* e = getenv("ISL_HBITS"); return e ? atoi(e) : 0; }();
   if (hbits_env >= 8 && hbits_env <= 14) hbits = (uint32_t)hbits_env;  // experiments only
   // visited table, merge buffer, query (+ 64 bytes when d is not a multiple of 16: the operand
   // prefetch of direct_group may touch the rest of the last step)
-  size_t lds = ((size_t)4 << hbits) + (size_t)mbuf_entries(ef) * 8 + (size_t)((d + 3) / 4 * 4) * 4 +
-               ((d & 15) ? 64 : 0);
+  size_t lds = ((size_t)4 << hbits) + (size_t)mbuf_entries(ef) * 8 +
+               (qbytes == 2 ? (size_t)((d + 7) / 8 * 8) * 2 + 64 : (size_t)((d + 3) / 4 * 4) * 4 + ((d & 15) ? 64 : 0));
   return {hbits, lds};
 }
 
@@ -180,11 +182,11 @@ isl_status prepare_workspace(isl::SearchWorkspace& ws, uint32_t nq, uint32_t slo
     ws.slots = slots;
   }
   if (ws.cap_q < nq) {
-    void* ptrs[] = {ws.status, ws.payload, ws.ctr, ws.redo, ws.replay};
+    void* ptrs[] = {ws.status, ws.payload, ws.ctr, ws.redo, ws.replay, ws.qsel};
     for (void* q : ptrs)
       if (q) (void)hipFree(q);
     ws.status = nullptr; ws.payload = nullptr; ws.ctr = nullptr; ws.redo = nullptr;
-    ws.replay = nullptr;
+    ws.replay = nullptr; ws.qsel = nullptr;
     ws.cap_q = 0;
     uint32_t cap = nq < 1024 ? 1024 : nq;
     ISL_TRY(lane_malloc(ws, ws.status, (size_t)cap * 4));
@@ -192,6 +194,7 @@ isl_status prepare_workspace(isl::SearchWorkspace& ws, uint32_t nq, uint32_t slo
     ISL_TRY(lane_malloc(ws, ws.ctr, (size_t)cap * 16));
     ISL_TRY(lane_malloc(ws, ws.redo, (size_t)cap * 4));
     ISL_TRY(lane_malloc(ws, ws.replay, (size_t)cap * 4));
+    ISL_TRY(lane_malloc(ws, ws.qsel, (size_t)cap * 4));
     ws.cap_q = cap;
   }
   uint64_t want_log = (uint64_t)ws.cap_q * plog_cap;
@@ -380,10 +383,22 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   // searches over the recompute provider park and resume on the fast kernel (f32 rows; the
   // two-level and heap-exact kernels re-run a blocked query from its start instead)
   const bool resume = !warm && ws.round_active != 0 && use_fast && !tl;
+  // bf16 rows: first the kernel that keeps the query as bf16 in LDS (half the LDS per wave, more
+  // waves per CU), then the float32-query kernel over the queries that one passed on
+  static const bool no_qh = getenv("ISL_NO_QH") != nullptr;  // A/B switch for measurements
+  const bool qh = use_fast && !tl && !resume && idx->d_emb16 && idx->max_degree <= 64 && !no_qh;
+  FastGeom fgq = fg;
+  uint32_t slots_q = slots;
+  if (qh) {
+    fgq = fast_geometry(ef, (uint32_t)d, 2);
+    slots_q = (uint32_t)isl::device_cu_count(idx->device) *
+              (uint32_t)std::max<size_t>(1, std::min<size_t>(waves_per_cu_cap(), (160 * 1024) / fgq.lds));
+  }
   // per-slot state is indexed by blockIdx.x < min(nq, slots) -- by the query when it can come back on
   // another wave
   if (!warm)
-    ISL_TRY(prepare_workspace(ws, (uint32_t)nq, (uint32_t)(idx->recompute ? nq : std::min<uint64_t>(nq, slots)), plog_cap));
+    ISL_TRY(prepare_workspace(ws, (uint32_t)nq,
+                              (uint32_t)(idx->recompute ? nq : std::min<uint64_t>(nq, std::max(slots, slots_q))), plog_cap));
   if (!idx->pool.slots || ((use_fast || (tl && idx->max_degree <= 128)) && !idx->d_ell && idx->d_off && idx->num_nodes)) {
     // not prepared (isl_index_prepare / isl_index_upload do this ahead of time)
     std::lock_guard<std::mutex> lock(idx->mu);
@@ -511,11 +526,23 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
     const int metric = (int)idx->cfg.metric;
     const bool wide = idx->max_degree > 64;
     const bool bf16 = p.emb_bf16 != 0;
-    switch (S) {
-      case 1: isl_launch::launch_fast_s1(metric, wide, bf16, resume, grid, fg.lds, st, &p); break;
-      case 2: isl_launch::launch_fast_s2(metric, wide, bf16, resume, grid, fg.lds, st, &p); break;
-      case 4: isl_launch::launch_fast_s4(metric, wide, bf16, resume, grid, fg.lds, st, &p); break;
-      default: isl_launch::launch_fast_s8(metric, wide, bf16, resume, grid, fg.lds, st, &p); break;
+    auto launch_fast = [&](bool q16, uint32_t g, size_t lds_bytes) {
+      switch (S) {
+        case 1: isl_launch::launch_fast_s1(metric, wide, bf16, resume, q16, g, lds_bytes, st, &p); break;
+        case 2: isl_launch::launch_fast_s2(metric, wide, bf16, resume, q16, g, lds_bytes, st, &p); break;
+        case 4: isl_launch::launch_fast_s4(metric, wide, bf16, resume, q16, g, lds_bytes, st, &p); break;
+        default: isl_launch::launch_fast_s8(metric, wide, bf16, resume, q16, g, lds_bytes, st, &p); break;
+      }
+    };
+    if (qh) {
+      p.qsel = ws.qsel;
+      launch_fast(true, (uint32_t)std::min<uint64_t>(nq_grid, slots_q), fgq.lds);
+      ISL_HIP(hipGetLastError());
+      p.qsel_mode = 1;  // whatever that launch listed (queries with elements that are not bf16 values)
+      launch_fast(false, grid, fg.lds);
+      p.qsel_mode = 0;
+    } else {
+      launch_fast(false, grid, fg.lds);
     }
     ISL_HIP(hipGetLastError());
     p.nq = (uint32_t)nq;

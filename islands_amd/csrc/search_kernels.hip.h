@@ -88,6 +88,11 @@ struct SearchParams {
   uint32_t qstate_words;  // per query
   uint32_t* qflag;        // [all queries] 1 = state parked
   const uint32_t* qlist;
+  // bf16 rows: the QH instantiation keeps the query in LDS as bf16 bit patterns; a query with an
+  // element that is not a bf16 value is listed in qsel (count in ticket[5]) and answered by the
+  // launch that follows with the float32-query kernel in list mode (qsel_mode = 1, head ticket[6])
+  uint32_t* qsel;
+  uint32_t qsel_mode;
   // HnswGraph facade (hnsw.rs): adjacency of the layers above 0 for the greedy descent
   const uint64_t* const* layer_off;  // [max_level + 1] device pointers (index 0 unused)
   const uint32_t* const* layer_adj;
@@ -569,8 +574,9 @@ __device__ __forceinline__ bool visited_insert(uint32_t* htab, uint32_t hbits, u
 // 64 at a time in CSR order -- the same sequential rule, run over two slices.
 // RESUME = searches over the recompute provider: a query that meets an absent row parks its whole
 // state and is taken up again, in the hop it stopped at, once the provider has encoded the row.
-template <int S, int METRIC_API, typename ROWT, bool WIDE, bool RESUME = false>
+template <int S, int METRIC_API, typename ROWT, bool WIDE, bool RESUME = false, bool QH = false>
 __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
+  static_assert(!QH || (sizeof(ROWT) == 2 && !RESUME), "the bf16 query operand goes with bf16 rows");
   constexpr uint32_t kMaxDeg = WIDE ? 128u : 64u;
   // parked state of one query, in words: 16 scalars, tie list, the hop's unvisited ids (2 x 64),
   // result set (S x (64 keys + 64 ids)), visited table
@@ -595,9 +601,22 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
 
   for (;;) {
     uint32_t qi = 0;
-    if (lane == 0) qi = atomicAdd(&p.ticket[0], 1u);
-    qi = uni(qi);
-    if (qi >= p.nq) break;
+    if constexpr (sizeof(ROWT) == 2 && !QH && !RESUME) {
+      if (p.qsel_mode) {  // the queries the bf16-query launch passed on
+        if (lane == 0) qi = atomicAdd(&p.ticket[6], 1u);
+        qi = uni(qi);
+        if (qi >= *((volatile uint32_t*)&p.ticket[5])) break;
+        qi = p.qsel[qi];
+      } else {
+        if (lane == 0) qi = atomicAdd(&p.ticket[0], 1u);
+        qi = uni(qi);
+        if (qi >= p.nq) break;
+      }
+    } else {
+      if (lane == 0) qi = atomicAdd(&p.ticket[0], 1u);
+      qi = uni(qi);
+      if (qi >= p.nq) break;
+    }
     if constexpr (RESUME) {
       if (p.qlist) qi = p.qlist[qi];
       otab = p.otab + (size_t)qi * ocap;  // a parked query may come back on another wave
@@ -619,7 +638,17 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
     }
     if (resumed) { for (uint32_t i = lane; i < hcap; i += 64) htab[i] = qst[kStTab + i]; }
     else { for (uint32_t i = lane; i < hcap; i += 64) htab[i] = EMPTY; }
-    const float q_norm = load_query<METRIC>(p.queries + (uint64_t)qi * p.d, p.d, qs);  // syncs
+    float q_norm;
+    if constexpr (QH) {
+      bool representable;
+      q_norm = load_query_bf16<METRIC>(p.queries + (uint64_t)qi * p.d, p.d, qs, &representable);  // syncs
+      if (!representable) {  // not a bf16-valued query: the float32-query launch behind this one takes it
+        if (lane == 0) p.qsel[atomicAdd(&p.ticket[5], 1u)] = qi;
+        continue;
+      }
+    } else {
+      q_norm = load_query<METRIC>(p.queries + (uint64_t)qi * p.d, p.d, qs);  // syncs
+    }
 
     RSet<S> rs;
     rs.init();
@@ -666,7 +695,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       const uint32_t entry = p.q_entry ? p.q_entry[qi] : p.entry;
       const uint32_t erow = row_index(p, entry, true);
       float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[erow] : 0.0f;
-      float ed = direct_distances<METRIC, ROWT>(emb, p.stride, p.d, erow, 1, qs, q_norm, e_aux);
+      float ed = direct_distances<METRIC, ROWT, QH>(emb, p.stride, p.d, erow, 1, qs, q_norm, e_aux);
       ed = rl_f(ed, 0);
       cV = p.q_entry ? p.q_evals[qi] : 1;
       if (lane == 0) htab[hslot(entry, p.hbits)] = entry;
@@ -828,7 +857,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       ngroups += (keep + 15) / 16;
       const uint32_t rix = row_index(p, uid, (uint32_t)lane < keep);
       float r_aux = (METRIC == METRIC_COSINE_PRE && (uint32_t)lane < keep) ? p.norm2[rix] : 0.0f;
-      float nd = direct_distances<METRIC, ROWT>(emb, p.stride, p.d, rix, keep, qs, q_norm, r_aux);
+      float nd = direct_distances<METRIC, ROWT, QH>(emb, p.stride, p.d, rix, keep, qs, q_norm, r_aux);
       ISL_MARK(tp2)  // row fetch + distances
 
       // leann.rs:953-970 in CSR order; worst = results.peek().  NaN / -0.0 distances have no
@@ -1587,11 +1616,12 @@ void launch_one(K kernel, uint32_t grid, size_t lds, hipStream_t st, const Searc
 // Launchers defined in the instantiating units; `params` points at a SearchParams (the struct is
 // the same text in every unit).
 namespace isl_launch {
-// resume = the RESUME instantiation (recompute provider; f32 rows only)
-void launch_fast_s1(int metric, bool wide, bool bf16, bool resume, uint32_t grid, size_t lds, hipStream_t st, const void* params);
-void launch_fast_s2(int metric, bool wide, bool bf16, bool resume, uint32_t grid, size_t lds, hipStream_t st, const void* params);
-void launch_fast_s4(int metric, bool wide, bool bf16, bool resume, uint32_t grid, size_t lds, hipStream_t st, const void* params);
-void launch_fast_s8(int metric, bool wide, bool bf16, bool resume, uint32_t grid, size_t lds, hipStream_t st, const void* params);
+// resume = the RESUME instantiation (recompute provider; f32 rows only); qh = the QH instantiation
+// (bf16 rows of up to 64 ids per adjacency row, query held as bf16 in LDS)
+void launch_fast_s1(int metric, bool wide, bool bf16, bool resume, bool qh, uint32_t grid, size_t lds, hipStream_t st, const void* params);
+void launch_fast_s2(int metric, bool wide, bool bf16, bool resume, bool qh, uint32_t grid, size_t lds, hipStream_t st, const void* params);
+void launch_fast_s4(int metric, bool wide, bool bf16, bool resume, bool qh, uint32_t grid, size_t lds, hipStream_t st, const void* params);
+void launch_fast_s8(int metric, bool wide, bool bf16, bool resume, bool qh, uint32_t grid, size_t lds, hipStream_t st, const void* params);
 // words of one parked query (RESUME) for result sets of S x 64 entries and a visited table of 1 << hbits
 inline uint32_t fast_state_words(int S, uint32_t hbits) { return 208u + (uint32_t)S * 128u + (1u << hbits); }
 void launch_exact(int metric, bool hnsw, uint32_t grid, size_t lds, hipStream_t st, const void* params);

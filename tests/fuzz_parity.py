@@ -62,11 +62,25 @@ def one_case(rng, case):
                     num_nodes=n, degree_counts=degs)
     idx = ia.LeannIndex.from_csr(g, cfg, dimension=d)
     idx.upload(0)
-    idx.set_embeddings(vec)
+    # a quarter of the cases store the rows as bf16 (the provider's vectors are then the exact f32
+    # images of the rounded values); of their queries some, all or none are bf16-valued, which picks
+    # between the two instantiations of the traversal kernel inside one call
+    as_bf16 = rng.random() < 0.25
+    if as_bf16:
+        b16 = (vec.view(np.uint32) >> 16).astype(np.uint16)
+        vec = (b16.astype(np.uint32) << 16).view(np.float32)
+        idx.set_embeddings_bf16(b16)
+        share = float(rng.choice([0.0, 0.5, 1.0]))
+        pick = rng.random(nq) < share
+        q = q.copy()
+        q[pick] = ((q[pick].view(np.uint32) >> 16) << 16).view(np.float32)
+    else:
+        idx.set_embeddings(vec)
     ids, dist, cnt = idx.search_batch(q, k, ef)
     st = idx.last_stats()
     tot = {"expansions": 0, "edges": 0, "evals": 0, "pushes": 0}
-    desc = f"case {case}: n={n} d={d} deg={deg} metric={metric} ef={ef} k={k} prune={ratio}/{strategy} quant={quant:.2f}"
+    desc = (f"case {case}: n={n} d={d} deg={deg} metric={metric} ef={ef} k={k} prune={ratio}/{strategy} "
+            f"quant={quant:.2f} bf16={as_bf16}")
     for i in range(nq):
         r = orc.leann_search(csr, vec, q[i], k, ef, metric=metric, prune_ratio=ratio, strategy=strategy)
         assert r.status == 0, desc

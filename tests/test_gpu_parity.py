@@ -486,6 +486,18 @@ def test_bf16_rows_match_oracle_on_widened_rows(orc, metric, d):
     for f in tot:
         assert st[f] == tot[f], f
     assert st["exact_path"] == 0
+    # Queries whose elements are bf16 values are answered by the instantiation that keeps the query
+    # as bf16 in LDS; the others are passed on to the float32-query kernel by the same call.  All
+    # bf16-valued, none (above), and a mix:
+    qb = widen(to_bf16_bits(clustered_vectors(24, d, 33)))
+    mix = qb.copy()
+    mix[::3] = clustered_vectors(24, d, 34)[::3]
+    mix[5, d - 1] = np.float32(1.0) + np.float32(2.0 ** -20)  # one stray element in the last position
+    for qq in (qb, mix):
+        st, tot = assert_same_search(orc, idx, csr, rows, qq, 10, 48, metric=int(metric))
+        for f in tot:
+            assert st[f] == tot[f], f
+        assert st["exact_path"] == 0
 
 
 def test_bf16_rows_ties_take_the_exact_kernel(orc):
