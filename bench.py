@@ -272,6 +272,8 @@ def main():
                 q = synth.make_uniform(nq, d, 43 + qoff, device=dev)
             else:
                 q = synth.make_rows(N, d, qoff, nq, per_cluster=args.per_cluster, device=dev, query=True)
+            if args.row_dtype == "bf16":  # config 5: the queries are bf16 values too (their exact f32 images)
+                q = q.to(torch.bfloat16).to(torch.float32)
             qsets.append(q.contiguous())
             ti, td = synth.brute_force_topk_native(x, q, k)  # exact truth: float32 MFMA brute force
             truths.append((ti + lo, td))

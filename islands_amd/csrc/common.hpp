@@ -62,6 +62,7 @@ struct SearchWorkspace {
   uint32_t* redo = nullptr;    // [cap_q] query ids routed to the exact kernel
   uint32_t* replay = nullptr;  // [cap_q] query ids routed to the replay kernel
   uint32_t* qsel = nullptr;    // [cap_q] bf16 rows: queries whose elements are not all bf16 values
+  uint32_t* qsel_h = nullptr;  // [cap_q] ... and the queries whose elements are
   uint64_t* plog = nullptr;    // [cap_q][plog_cap] push log (distance bits, id)
   uint64_t plog_entries = 0;
   // staging for the host-pointer entry points: device side ...

@@ -37,6 +37,12 @@ FastGeom fast_geometry(uint32_t ef, uint32_t d, uint32_t qbytes = 4) {
   // visited capacity grows with ef (V is roughly 10-30 x ef); overflow goes to HBM
   uint32_t hbits = ef <= 64 ? 10 : ef <= 160 ? 11 : ef <= 320 ? 12 : 13;
   static const int hbits_env = [] { const char* e = getenv("ISL_HBITS"); return e ? atoi(e) : 0; }();
+  // A long query takes most of a wave's LDS (d = 4096: 16 KB as float32, 8 KB as bf16) and the waves
+  // per CU with it; once it is at least as large as the visited table, half a table buys more
+  // through occupancy than it costs through the overflow table in HBM (10M x 4096 bf16 rows,
+  // ef = 128: 0.40 -> 0.45 of the HBM peak).  At d = 768 the full table wins and stays.
+  const size_t qlds = (size_t)d * qbytes;
+  if (qlds >= ((size_t)4 << hbits) && hbits > 9) hbits -= 1;
   if (hbits_env >= 8 && hbits_env <= 14) hbits = (uint32_t)hbits_env;  // experiments only
   // visited table, merge buffer, query (+ 64 bytes when d is not a multiple of 16: the operand
   // prefetch of direct_group may touch the rest of the last step)
@@ -182,11 +188,11 @@ isl_status prepare_workspace(isl::SearchWorkspace& ws, uint32_t nq, uint32_t slo
     ws.slots = slots;
   }
   if (ws.cap_q < nq) {
-    void* ptrs[] = {ws.status, ws.payload, ws.ctr, ws.redo, ws.replay, ws.qsel};
+    void* ptrs[] = {ws.status, ws.payload, ws.ctr, ws.redo, ws.replay, ws.qsel, ws.qsel_h};
     for (void* q : ptrs)
       if (q) (void)hipFree(q);
     ws.status = nullptr; ws.payload = nullptr; ws.ctr = nullptr; ws.redo = nullptr;
-    ws.replay = nullptr; ws.qsel = nullptr;
+    ws.replay = nullptr; ws.qsel = nullptr; ws.qsel_h = nullptr;
     ws.cap_q = 0;
     uint32_t cap = nq < 1024 ? 1024 : nq;
     ISL_TRY(lane_malloc(ws, ws.status, (size_t)cap * 4));
@@ -195,6 +201,7 @@ isl_status prepare_workspace(isl::SearchWorkspace& ws, uint32_t nq, uint32_t slo
     ISL_TRY(lane_malloc(ws, ws.redo, (size_t)cap * 4));
     ISL_TRY(lane_malloc(ws, ws.replay, (size_t)cap * 4));
     ISL_TRY(lane_malloc(ws, ws.qsel, (size_t)cap * 4));
+    ISL_TRY(lane_malloc(ws, ws.qsel_h, (size_t)cap * 4));
     ws.cap_q = cap;
   }
   uint64_t want_log = (uint64_t)ws.cap_q * plog_cap;
@@ -536,9 +543,12 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
     };
     if (qh) {
       p.qsel = ws.qsel;
-      launch_fast(true, (uint32_t)std::min<uint64_t>(nq_grid, slots_q), fgq.lds);
+      p.qsel_h = ws.qsel_h;
+      isl_launch::launch_classify((uint32_t)std::min<uint64_t>(nq_grid, 2048), st, &p);
       ISL_HIP(hipGetLastError());
-      p.qsel_mode = 1;  // whatever that launch listed (queries with elements that are not bf16 values)
+      launch_fast(true, (uint32_t)std::min<uint64_t>(nq_grid, slots_q), fgq.lds);  // the bf16-valued queries
+      ISL_HIP(hipGetLastError());
+      p.qsel_mode = 1;  // the others
       launch_fast(false, grid, fg.lds);
       p.qsel_mode = 0;
     } else {

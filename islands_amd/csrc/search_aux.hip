@@ -43,3 +43,8 @@ void isl_launch::launch_descent(int metric, uint32_t grid, size_t lds, hipStream
     default: launch_one(hnsw_descent_kernel<ISL_METRIC_MANHATTAN>, grid, lds, st, p); break;
   }
 }
+
+void isl_launch::launch_classify(uint32_t grid, hipStream_t st, const void* params) {
+  const SearchParams& p = *static_cast<const SearchParams*>(params);
+  hipLaunchKernelGGL(classify_queries_kernel, dim3(grid), dim3(64), 0, st, p);
+}

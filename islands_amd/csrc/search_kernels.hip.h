@@ -88,10 +88,12 @@ struct SearchParams {
   uint32_t qstate_words;  // per query
   uint32_t* qflag;        // [all queries] 1 = state parked
   const uint32_t* qlist;
-  // bf16 rows: the QH instantiation keeps the query in LDS as bf16 bit patterns; a query with an
-  // element that is not a bf16 value is listed in qsel (count in ticket[5]) and answered by the
-  // launch that follows with the float32-query kernel in list mode (qsel_mode = 1, head ticket[6])
+  // bf16 rows: classify_queries_kernel sorts the batch into the queries whose elements are all bf16
+  // values (qsel_h, count ticket[7], head ticket[4]: answered by the QH instantiation, which keeps
+  // the query in LDS as bf16 bit patterns) and the others (qsel, count ticket[5], head ticket[6]:
+  // the float32-query kernel in list mode, qsel_mode = 1)
   uint32_t* qsel;
+  uint32_t* qsel_h;
   uint32_t qsel_mode;
   // HnswGraph facade (hnsw.rs): adjacency of the layers above 0 for the greedy descent
   const uint64_t* const* layer_off;  // [max_level + 1] device pointers (index 0 unused)
@@ -568,6 +570,20 @@ __device__ __forceinline__ bool visited_insert(uint32_t* htab, uint32_t hbits, u
   return fresh;
 }
 
+// bf16 rows: which queries of the batch consist of bf16 values only (one wave per query)
+__global__ __launch_bounds__(64) void classify_queries_kernel(SearchParams p) {
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t qi = blockIdx.x; qi < p.nq; qi += gridDim.x) {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p.queries + (uint64_t)qi * p.d);
+    bool bad = false;
+    for (uint32_t j = lane; j < p.d; j += 64) bad |= (q[j] & 0xFFFFu) != 0u;
+    if (lane == 0) {
+      if (ballot(bad)) p.qsel[atomicAdd(&p.ticket[5], 1u)] = qi;
+      else p.qsel_h[atomicAdd(&p.ticket[7], 1u)] = qi;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ fast kernel
 // WIDE = adjacency rows of up to 128 ids (LeannConfig::accurate() has m0 = 96, leann.rs:419-429):
 // a lane then holds two ids of the row, and the kept neighbours of a hop are evaluated and inserted
@@ -612,6 +628,11 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
         qi = uni(qi);
         if (qi >= p.nq) break;
       }
+    } else if constexpr (QH) {
+      if (lane == 0) qi = atomicAdd(&p.ticket[4], 1u);
+      qi = uni(qi);
+      if (qi >= *((volatile uint32_t*)&p.ticket[7])) break;
+      qi = p.qsel_h[qi];
     } else {
       if (lane == 0) qi = atomicAdd(&p.ticket[0], 1u);
       qi = uni(qi);
@@ -642,7 +663,7 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
     if constexpr (QH) {
       bool representable;
       q_norm = load_query_bf16<METRIC>(p.queries + (uint64_t)qi * p.d, p.d, qs, &representable);  // syncs
-      if (!representable) {  // not a bf16-valued query: the float32-query launch behind this one takes it
+      if (!representable) {  // (cannot happen after classify_queries_kernel; kept as a guard)
         if (lane == 0) p.qsel[atomicAdd(&p.ticket[5], 1u)] = qi;
         continue;
       }
@@ -1627,4 +1648,5 @@ inline uint32_t fast_state_words(int S, uint32_t hbits) { return 208u + (uint32_
 void launch_exact(int metric, bool hnsw, uint32_t grid, size_t lds, hipStream_t st, const void* params);
 void launch_two_level(int metric, bool bf16, uint32_t grid, size_t lds, hipStream_t st, const void* params);
 void launch_descent(int metric, uint32_t grid, size_t lds, hipStream_t st, const void* params);
+void launch_classify(uint32_t grid, hipStream_t st, const void* params);
 }  // namespace isl_launch
