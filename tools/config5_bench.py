@@ -43,8 +43,8 @@ def main():
     ap.add_argument("--ef", type=int, default=128)
     ap.add_argument("--pq-m", type=int, default=64)
     ap.add_argument("--ratio", type=float, default=0.3, help="re-rank ratio of the two-level search")
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--depth", type=int, default=6)
     ap.add_argument("--skip-two-level", action="store_true")
     ap.add_argument("--graph-only", action="store_true", help="stop after the graph (harness check)")
     a = ap.parse_args()
