@@ -159,8 +159,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const void* __restrict__ Av,
 // touch 16 different 16-byte slots of the 256-byte bank row).  Requirements (host-checked): A and W bf16,
 // K % 64 == 0; rows past M / N are clamped (their products are never stored).  Workgroup ids are
 // remapped so that the column tiles of one row tile share an XCD (its L2 then serves A once).
-typedef __attribute__((address_space(3))) void isl_lds_void;
-typedef const __attribute__((address_space(1))) void isl_glb_void;
+// (isl_lds_void / isl_glb_void: gemm_f32.hip.h)
 
 // WM x WN waves, each owning MF x NF blocks of 32 x 32: tile = (32 MF WM) x (32 NF WN).
 //   <2,2,2,2>: 128 x 128, 256 threads, 64 KiB LDS, two workgroups per CU;

@@ -135,9 +135,270 @@ __global__ __launch_bounds__(256) void gemm_tn_f32(const float* __restrict__ A,
     }
 }
 
+// The same contraction with both operands staged by LDS-DMA (global_load_lds_dwordx4, no register
+// stop) into two buffers of 32-deep slabs -- the arrangement of gemm_tn_bf16_dma (gemm_bf16.hip.h) for
+// float32 operands.  A float32 MFMA takes 64 cycles, so a 256 x 256 x 32 slab is 128 MFMAs = 8192
+// matrix-pipe cycles per wave: one barrier and one DMA round trip per slab disappear behind it, and
+// a lane fetches its operands with one ds_read_b128 per four MFMAs instead of one ds_read_b32 per
+// MFMA.  LDS image: row r = 128 bytes, 16-byte chunk c stored at c ^ ((r >> 1) & 7).  The k pairing
+// of v_mfma_f32_32x32x2_f32 (lanes 0..31 supply one k, lanes 32..63 another) is (8m + e, 8m + 4 + e):
+// lane half kh reads chunk 2m + kh and feeds its element e to MFMA e of step m.  The order in
+// which an output element accumulates its products depends on K alone -- not on the tile variant,
+// the position in the tile or M -- so an embedding does not depend on what it is batched with.
+// Requirements (host-checked): K % 32 == 0, 16-byte aligned operands; rows past M / N are clamped.
+typedef __attribute__((address_space(3))) void isl_lds_void;
+typedef const __attribute__((address_space(1))) void isl_glb_void;
+constexpr int FBK = 32;  // floats per slab row
+
+// EXP (tools/microbench/gemm_f32_exp.hip only): bit 0 = per-element epilogue stores, bit 1 = no staggered start.
+template <int ACT, bool RES, int WM, int WN, int MF, int NF, int EXP = 0>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_tn_f32_dma(const float* __restrict__ A,
+                                                                const float* __restrict__ W,
+                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ R,
+                                                                float* __restrict__ C, uint32_t M, uint32_t N,
+                                                                uint32_t K, uint32_t ntn, uint64_t ldc,
+                                                                uint32_t ntiles) {
+  constexpr uint32_t TM = 32 * MF * WM, TN = 32 * NF * WN, NW = WM * WN;
+  constexpr uint32_t ABYTES = TM * FBK * 4, WBYTES = TN * FBK * 4, BUF = ABYTES + WBYTES;
+  constexpr int NIA = TM * 8 / (64 * NW), NIW = TN * 8 / (64 * NW);  // DMA instructions per wave and slab
+  constexpr int NP = NIA + NIW, STEPS = FBK / 8;
+  constexpr uint32_t SCRATCH = 32 * 32 * NF * 4;  // the epilogue's transposing scratch per wave: 32 rows of the wave's columns
+  static_assert(NP % STEPS == 0, "pieces are spread evenly over the steps of a slab");
+  static_assert(NW * SCRATCH <= BUF, "the epilogue's scratch fits the buffer of the tile's last slab");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // [2][A slab | W slab]
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t kh = lane >> 5, c32 = lane & 31;
+  const uint32_t wm = (wave / WN) * (32 * MF), wn = (wave % WN) * (32 * NF);
+  const uint32_t nk = K / FBK;
+  // Tile t of the (virtual) grid of ntiles workgroups: an XCD-aware, bijective remap of the linear id
+  // (8 XCDs, round-robin dispatch; a persistent workgroup's tiles t, t + gridDim.x, ... stay on its XCD
+  // when gridDim.x is a multiple of 8); inside an XCD's range the resident workgroups cover 8 row
+  // tiles x a few column tiles.
+  auto tile_origin = [&](uint32_t t, uint64_t& m0, uint64_t& n0) {
+    const uint32_t q8 = ntiles / 8, r8 = ntiles % 8, xcd = t % 8;
+    const uint32_t wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + t / 8;
+    const uint32_t ntm = ntiles / ntn;
+    constexpr uint32_t GM = 8;
+    const uint32_t group = wgid / (GM * ntn), in_group = wgid % (GM * ntn);
+    const uint32_t gm = ntm - group * GM < GM ? ntm - group * GM : GM;
+    m0 = (uint64_t)(group * GM + in_group % gm) * TM;
+    n0 = (uint64_t)(in_group / gm) * TN;
+  };
+  const float* asrc[NIA];
+  const float* wsrc[NIW];
+  auto set_sources = [&](uint64_t m0, uint64_t n0) {
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const uint32_t chunk = (NW * i + wave) * 64u + lane, row = chunk >> 3, c = (chunk & 7u) ^ ((row >> 1) & 7u);
+      const uint64_t ra = m0 + row < M ? m0 + row : (uint64_t)M - 1;
+      asrc[i] = A + ra * K + c * 4u;
+    }
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+      const uint32_t chunk = (NW * i + wave) * 64u + lane, row = chunk >> 3, c = (chunk & 7u) ^ ((row >> 1) & 7u);
+      const uint64_t rw = n0 + row < N ? n0 + row : (uint64_t)N - 1;
+      wsrc[i] = W + rw * K + c * 4u;
+    }
+  };
+  // DMA piece p of a slab (the A pieces first): 1 KiB = 8 rows per wave instruction
+  auto piece = [&](int p, uint32_t k0, uint32_t buf) {
+    unsigned char* ab = lds + buf * BUF;
+    if (p < NIA)
+      __builtin_amdgcn_global_load_lds((isl_glb_void*)(asrc[p] + k0), (isl_lds_void*)(ab + (NW * p + wave) * 1024u), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((isl_glb_void*)(wsrc[p - NIA] + k0),
+                                       (isl_lds_void*)(ab + ABYTES + (NW * (p - NIA) + wave) * 1024u), 16, 0, 0);
+  };
+  // the fragments of step ms of a slab image: lane half kh reads 16-byte chunk 2 ms + kh (k = 8 ms + 4 kh + e)
+  auto frags = [&](const unsigned char* ab, int ms, float4 (&a)[MF], float4 (&b)[NF]) {
+    const unsigned char* wb = ab + ABYTES;
+    const uint32_t cl = 2 * ms + kh;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+      const uint32_t rb = wn + 32 * j + c32;
+      b[j] = *reinterpret_cast<const float4*>(wb + rb * 128u + ((cl ^ ((rb >> 1) & 7u)) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+      const uint32_t ra = wm + 32 * i + c32;
+      a[i] = *reinterpret_cast<const float4*>(ab + ra * 128u + ((cl ^ ((ra >> 1) & 7u)) << 4));
+    }
+  };
+  auto finish = [&](float v, uint64_t m, uint64_t n, float bv) -> float {  // the epilogue of one element
+    if (ACT <= 2) {
+      v += bv;
+      if (ACT == 1) v = gelu_erf_f(v);
+      if (ACT == 2) v = gelu_tanh_f(v);
+      if (RES) v += R[m * N + n];
+    } else if (ACT == EPI_COSINE) {
+      const float norm = sqrtf(R[m] * bv);
+      v = norm == 0.0f ? 1.0f : 1.0f - v / norm;
+    } else if (ACT == EPI_DOT) {
+      v = -v;
+    } else if (ACT == EPI_EUCLIDEAN) {
+      v = R[m] + bv - 2.0f * v;
+      v = sqrtf(v > 0.0f ? v : 0.0f);
+    }
+    return v;
+  };
+  const bool vec_ok = (N & 3u) == 0 && (ldc & 3u) == 0 && ((uintptr_t)C & 15u) == 0 && (!bias || ((uintptr_t)bias & 15u) == 0);
+
+  uint32_t t = blockIdx.x, par = 0;
+  uint64_t m0, n0;
+  tile_origin(t, m0, n0);
+  set_sources(m0, n0);
+  if (!(EXP & 2) && gridDim.x < ntiles) {
+    // Equal tiles keep the CUs in lockstep, and then every CU writes its 256 KiB of results in the same
+    // few microseconds: a burst the HBM write path cannot absorb while the matrix cores idle.  The
+    // workgroups start up to ~45 us apart so that the epilogues spread over the tile time.
+    const uint32_t naps = (blockIdx.x * 37u) % 12u;
+    for (uint32_t z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(127);
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) piece(p, 0, 0);
+  for (;;) {
+    floatx16 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const uint32_t tnext = t + gridDim.x;
+    const bool has_next = tnext < ntiles;
+    uint64_t nm0 = 0, nn0 = 0;
+    for (uint32_t kt = 0; kt < nk; ++kt) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of the slab has landed
+      __syncthreads();  // everyone's share has; everyone is done with the other buffer
+      const bool more = kt + 1 < nk;
+      if (!more && has_next) {  // the last slab's shadow covers the next tile's first slab
+        tile_origin(tnext, nm0, nn0);
+        set_sources(nm0, nn0);
+      }
+      const bool fetch = more || has_next;
+      const uint32_t knext = more ? (kt + 1) * FBK : 0u, bnext = (par + kt + 1) & 1u;
+      const unsigned char* cur = lds + ((par + kt) & 1u) * BUF;
+#pragma unroll
+      for (int ms = 0; ms < STEPS; ++ms) {
+        float4 a[MF], b[NF];
+        frags(cur, ms, a, b);
+        // e outermost: consecutive MFMAs go to different accumulators; an element still receives its
+        // products in ascending (step, e) order
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(e == 0 ? a[i].x : e == 1 ? a[i].y : e == 2 ? a[i].z : a[i].w,
+                                                               e == 0 ? b[j].x : e == 1 ? b[j].y : e == 2 ? b[j].z : b[j].w,
+                                                               acc[i][j], 0, 0, 0);
+          // the next slab's DMA pieces go out in the shadow of this step's MFMAs, not in a burst behind the barrier
+          if (e == 0 && fetch) {
+#pragma unroll
+            for (int p = ms * (NP / STEPS); p < (ms + 1) * (NP / STEPS); ++p) piece(p, knext, bnext);
+          }
+        }
+      }
+    }
+    if (EXP & 1) {
+#pragma unroll
+      for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          const uint64_t n = n0 + wn + j * 32 + c32;
+          if (n >= N) continue;
+          const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const uint64_t m = m0 + wm + i * 32 + 8 * (r / 4) + 4 * kh + (r % 4);
+            if (m >= M) continue;
+            C[m * ldc + n] = finish(acc[i][j][r], m, n, bv);
+          }
+        }
+    } else {
+      // Epilogue through LDS: an accumulator register holds one element of 16 different rows, so stored
+      // as is a wave instruction writes 2 x 128 bytes; transposed through the wave's own 8 KiB of the
+      // buffer the tile's last slab occupied, it writes 4 x 256 contiguous bytes (dwordx4 per lane).
+      __syncthreads();  // everyone is done reading the last slab
+      float* sc = reinterpret_cast<float*>(lds + ((par + nk - 1) & 1u) * BUF + wave * SCRATCH);
+      constexpr uint32_t WCOLS = 32 * NF;  // the wave's columns
+#pragma unroll
+      for (int i = 0; i < MF; ++i) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[(8 * (r / 4) + 4 * kh + (r % 4)) * WCOLS + 32 * j + c32] = acc[i][j][r];
+        // (LDS operations of one wave complete in order: the reads below see the writes above)
+#pragma unroll
+        for (uint32_t q = 0; q < 32 * WCOLS / 256; ++q) {
+          const uint32_t e4 = q * 64 + lane, row = e4 / (WCOLS / 4), c4 = e4 % (WCOLS / 4);
+          const float4 v = *reinterpret_cast<const float4*>(sc + row * WCOLS + 4 * c4);
+          const uint64_t m = m0 + wm + 32 * i + row, n = n0 + wn + 4 * c4;
+          if (m >= M || n >= N) continue;
+          if (vec_ok) {
+            const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n) : float4{0.0f, 0.0f, 0.0f, 0.0f};
+            float4 o;
+            o.x = finish(v.x, m, n, bv.x);
+            o.y = finish(v.y, m, n + 1, bv.y);
+            o.z = finish(v.z, m, n + 2, bv.z);
+            o.w = finish(v.w, m, n + 3, bv.w);
+            *reinterpret_cast<float4*>(C + m * ldc + n) = o;
+          } else {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (n + u < N) C[m * ldc + n + u] = finish(vv[u], m, n + u, bias ? bias[n + u] : 0.0f);
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    par = (par + nk) & 1u;
+    t = tnext;
+    m0 = nm0;
+    n0 = nn0;
+  }
+}
+
 template <int ACT, bool RES>
 void launch_gemm(const float* A, const float* W, const float* bias, const float* R, float* C,
                  uint64_t M, uint64_t N, uint64_t K, hipStream_t st) {
+  static const bool no_dma = getenv("ISL_GEMM_F32_NO_DMA") != nullptr;  // A/B switch for measurements
+  if (!no_dma && K % FBK == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0) {
+    // the 256 x 256 tile needs enough tiles to fill the chip; both variants add an element's products
+    // in the same order
+    const uint64_t big = ((M + 255) / 256) * ((N + 255) / 256);
+    static const uint32_t cus = [] {
+      int dev = 0, n = 0;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      return (uint32_t)(n > 0 ? n : 256);
+    }();
+    if (big >= 384) {
+      // persistent: one workgroup per CU (128 KiB of LDS each) walks its tiles, the next tile's first
+      // slab in flight under the current tile's last
+      auto kern = gemm_tn_f32_dma<ACT, RES, 2, 4, 4, 2>;
+      constexpr size_t lds = 2 * (256 + 256) * FBK * 4;
+      static const bool once = [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return true;
+      }();
+      (void)once;
+      const uint32_t grid = (uint32_t)(big < cus ? big : cus);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, W, bias, R, C, (uint32_t)M, (uint32_t)N,
+                         (uint32_t)K, (uint32_t)((N + 255) / 256), N, (uint32_t)big);
+    } else {
+      const uint64_t ntm = (M + 127) / 128, ntn = (N + 127) / 128;
+      auto kern = gemm_tn_f32_dma<ACT, RES, 2, 2, 2, 2>;
+      constexpr size_t lds = 2 * (128 + 128) * FBK * 4;
+      const uint32_t grid = (uint32_t)(ntm * ntn < 2 * cus ? ntm * ntn : 2 * cus);  // two workgroups fit a CU
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A, W, bias, R, C, (uint32_t)M,
+                         (uint32_t)N, (uint32_t)K, (uint32_t)ntn, N, (uint32_t)(ntm * ntn));
+    }
+    return;
+  }
   dim3 grid((uint32_t)((N + BN - 1) / BN), (uint32_t)((M + BM - 1) / BM));
   hipLaunchKernelGGL((gemm_tn_f32<ACT, RES>), grid, dim3(256), 0, st, A, W, bias, R, C, (uint32_t)M,
                      (uint32_t)N, (uint32_t)K);

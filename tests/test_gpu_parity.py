@@ -413,6 +413,25 @@ def test_pq_matches_oracle(orc):  # pq.rs:639-677, 787-809, 505-520
 
 
 # ------------------------------------------------ distance matrix on the matrix cores
+@pytest.mark.parametrize("nq,n,d", [(300, 1030, 32), (513, 1024, 96), (700, 131074, 64), (600, 100001, 96)])
+def test_distance_matrix_tile_walk(orc, nq, n, d):
+    """The LDS-DMA float32 GEMM (d % 32 == 0): one slab and several, row counts that are and are not
+    multiples of 4 (vector and per-element epilogue), ragged last tiles, and -- the two large cases --
+    the persistent 256 x 256 variant whose workgroups walk several tiles with an even and an odd
+    number of slabs (the buffer parity carried from tile to tile).  Whole matrix against a float64
+    product, sampled query rows against the reference's batch_calculate."""
+    rows = clustered_vectors(n, d, 13)
+    q = clustered_vectors(nq, d, 14)
+    got = ia.distance_matrix(ia.DistanceMetric.Cosine, q, rows)
+    qn = np.sqrt((q.astype(np.float64) ** 2).sum(1))
+    rn = np.sqrt((rows.astype(np.float64) ** 2).sum(1))
+    want = 1.0 - (q.astype(np.float64) @ rows.astype(np.float64).T) / (qn[:, None] * rn[None, :])
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 1e-5
+    for i in (0, nq // 2, nq - 1):
+        assert np.abs(got[i] - orc.batch_distance(int(ia.DistanceMetric.Cosine), q[i], rows)).max() < 1e-5
+
+
 @pytest.mark.parametrize("metric", [ia.DistanceMetric.Cosine, ia.DistanceMetric.DotProduct,
                                     ia.DistanceMetric.Euclidean])
 @pytest.mark.parametrize("nq,n,d", [(5, 300, 128), (130, 257, 768), (3, 70, 30)])
