@@ -334,6 +334,8 @@ def main():
                 if len(pending) >= depth:
                     b, tok = pending.pop(0)
                     st, res = finish(b, tok)
+                    if trace is not None:
+                        trace.append((b, time.perf_counter(), st["kernel_ms"]))
                     for f in agg:
                         agg[f] += st[f]
                     if collect and len(kept) < nb_batches:
@@ -341,18 +343,25 @@ def main():
             while pending:
                 b, tok = pending.pop(0)
                 st, res = finish(b, tok)
+                if trace is not None:
+                    trace.append((b, time.perf_counter(), st["kernel_ms"]))
                 for f in agg:
                     agg[f] += st[f]
                 if collect and len(kept) < nb_batches:
                     kept.append((b % nb_batches, res[0].clone(), res[1].clone()))
             return agg, kept
 
+        trace = None
         run(0, args.warmup, False)
         barrier()
+        trace = [] if os.environ.get("ISL_BENCH_TRACE") else None  # completion times of the timed steps -> stderr
         t0 = time.perf_counter()
         agg, recalls = run(args.warmup, args.steps, True)
         barrier()
         elapsed = time.perf_counter() - t0
+        if trace:
+            log("step completions (ms after the start of the timed region; kernel ms of the step): " +
+                " ".join(f"{b}:{(t - t0) * 1e3:.2f}/{km:.2f}" for b, t, km in trace) + f"  end {elapsed * 1e3:.2f}")
         if shard_mode:
             searcher.check_flags()
         if world > 1:

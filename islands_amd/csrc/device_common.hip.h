@@ -5,6 +5,8 @@
 // coalesced 16-byte loads).
 // Translation units including this file must be built with -ffp-contract=off.
 #pragma once
+#include <type_traits>
+#include <utility>
 
 #include "common.hpp"
 
@@ -87,7 +89,22 @@ __device__ __forceinline__ float quad_bcast(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), SEL * 0x55, 0xf, 0xf, true));
 }
 
+// value of `v` in the previous lane of the caller's quad (lane 0 takes lane 3's): DPP
+// quad_perm:[3,0,1,2], folds into the consuming v_add_f32 as its DPP source operand
+__device__ __forceinline__ float quad_prev(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x93, 0xf, 0xf, true));
+}
+
 // ------------------------------------------------------- exact-order distances
+// The quad chain.  Lane s of a quad owns elements 16i + 4s .. 16i + 4s + 3 of its row (8 per lane
+// and 32 per step for bf16 rows).  The partial sum travels round the quad: in turn t of a step lane
+// t takes it from lane t - 1 (one v_add_f32 with a DPP source, 12.3 cycles when the chain depends
+// on it) and adds its own elements with plain adds (5.25 cycles each) -- (12.3 + 3 x 5.25) / 4 = 7
+// cycles per element where a chain that fetches every addend from the owning lane
+// (v_add_f32_dpp quad_perm:[s,s,s,s], round 1) paid 14.5.  All four lanes execute every turn; the
+// three that do not hold the live sum compute values nobody reads.  After a whole step the sum sits
+// in lane 3, which is where the caller broadcasts it from (quad_bcast<3>).  The order of the
+// additions is the reference's: element 0, 1, 2, ... of the row.
 // One step of the reference's scalar loops (distance.rs:71-122); q = query element
 // (a), x = row element (b).  Separate roundings: this file is built -ffp-contract=off.
 template <int METRIC>
@@ -181,11 +198,14 @@ __device__ __forceinline__ float group_distances(const float* __restrict__ emb, 
   // dependent adds take their addend straight from the owning lane (v_add_f32_dpp quad_perm).
   // The dependent add (about 14.5 cycles on gfx950) is the critical path either way; what this
   // layout buys is issue slots: 1.25 VALU and 0.125 LDS instructions per element, not 2 and 0.5.
-#define ISL_ADD(ss, c)                                                           \
-  a0 += quad_bcast<ss>(p##c);                                                     \
-  if constexpr (METRIC == ISL_METRIC_COSINE) a1 += quad_bcast<ss>(n##c);
-#define ISL_ADD_G(ss, c) if (j + 4 * (ss) + (c) < cnt) { ISL_ADD(ss, c) }
-#define ISL_QUARTER(A, ss) A(ss, 0) A(ss, 1) A(ss, 2) A(ss, 3)
+#define ISL_TURN(ss)                                                                          \
+  a0 = quad_prev(a0) + p0; a0 += p1; a0 += p2; a0 += p3;                                       \
+  if constexpr (METRIC == ISL_METRIC_COSINE) { a1 = quad_prev(a1) + n0; a1 += n1; a1 += n2; a1 += n3; }
+#define ISL_ADD_G1(ss, c) if (j + 4 * (ss) + (c) < cnt) { a0 += p##c; if constexpr (METRIC == ISL_METRIC_COSINE) a1 += n##c; }
+#define ISL_TURN_G(ss)                                                                        \
+  a0 = quad_prev(a0);                                                                          \
+  if constexpr (METRIC == ISL_METRIC_COSINE) a1 = quad_prev(a1);                               \
+  ISL_ADD_G1(ss, 0) ISL_ADD_G1(ss, 1) ISL_ADD_G1(ss, 2) ISL_ADD_G1(ss, 3)
 #define ISL_TERMS                                                                              \
   const float p0 = dterm<METRIC>(q.x, x.x), p1 = dterm<METRIC>(q.y, x.y),                      \
               p2 = dterm<METRIC>(q.z, x.z), p3 = dterm<METRIC>(q.w, x.w);                      \
@@ -203,7 +223,7 @@ __device__ __forceinline__ float group_distances(const float* __restrict__ emb, 
           const float4 x = *reinterpret_cast<const float4*>(trow + j);
           const float4 q = *reinterpret_cast<const float4*>(qv + j);
           ISL_TERMS
-          ISL_QUARTER(ISL_ADD, 0) ISL_QUARTER(ISL_ADD, 1) ISL_QUARTER(ISL_ADD, 2) ISL_QUARTER(ISL_ADD, 3)
+          ISL_TURN(0) ISL_TURN(1) ISL_TURN(2) ISL_TURN(3)
         }
       } else {
         for (uint32_t j = 0; j < cnt; j += 16) {
@@ -214,14 +234,14 @@ __device__ __forceinline__ float group_distances(const float* __restrict__ emb, 
           }
           ISL_TERMS
           // elements at or past `cnt` (stale tile / query words) are multiplied but never added
-          ISL_QUARTER(ISL_ADD_G, 0) ISL_QUARTER(ISL_ADD_G, 1) ISL_QUARTER(ISL_ADD_G, 2) ISL_QUARTER(ISL_ADD_G, 3)
+          ISL_TURN_G(0) ISL_TURN_G(1) ISL_TURN_G(2) ISL_TURN_G(3)
         }
       }
     }
   };
-#undef ISL_ADD
-#undef ISL_ADD_G
-#undef ISL_QUARTER
+#undef ISL_TURN
+#undef ISL_ADD_G1
+#undef ISL_TURN_G
 #undef ISL_TERMS
   {
     const size_t poff = 0;
@@ -273,6 +293,8 @@ __device__ __forceinline__ float group_distances(const float* __restrict__ emb, 
 #undef ISL_STORE_A
 #undef ISL_STORE_B
 #undef ISL_STORE_C
+  a0 = quad_bcast<3>(a0);  // the sums end their round in lane 3
+  a1 = quad_bcast<3>(a1);
   if (METRIC == METRIC_COSINE_PRE) a1 = __shfl(row_aux, (int)((g0 + (lane >> 2)) & 63));
   return dfinish<METRIC>(a0, a1, q_norm);
 }
@@ -326,11 +348,15 @@ __device__ __forceinline__ float direct_group(const float* __restrict__ emb, uin
     const float* qp = qs + s4;
     const uint32_t nF = d >> 4;          // steps whose 16 elements all exist
     const uint32_t nS = (d + 15u) >> 4;  // steps in total
-#define ISL_ADD(ss, c)                                                           \
-  a0 += quad_bcast<ss>(p##c);                                                     \
-  if constexpr (METRIC == ISL_METRIC_COSINE) a1 += quad_bcast<ss>(n##c);
-#define ISL_ADD_G(ss, c) if (e0 + 4 * (ss) + (c) < d) { ISL_ADD(ss, c) }
-#define ISL_QUARTER(A, ss) A(ss, 0) A(ss, 1) A(ss, 2) A(ss, 3)
+#define ISL_TURN(ss)                                                                          \
+  a0 = quad_prev(a0) + p0; a0 += p1; a0 += p2; a0 += p3;                                       \
+  if constexpr (METRIC == ISL_METRIC_COSINE) { a1 = quad_prev(a1) + n0; a1 += n1; a1 += n2; a1 += n3; }
+#define ISL_ADD_G1(ss, c) if (e0 + 4 * (ss) + (c) < d) { a0 += p##c; if constexpr (METRIC == ISL_METRIC_COSINE) a1 += n##c; }
+#define ISL_TURN_G(ss)                                                                        \
+  a0 = quad_prev(a0);                                                                          \
+  if constexpr (METRIC == ISL_METRIC_COSINE) a1 = quad_prev(a1);                               \
+  ISL_ADD_G1(ss, 0) ISL_ADD_G1(ss, 1) ISL_ADD_G1(ss, 2) ISL_ADD_G1(ss, 3)
+#define ISL_ALL_TURNS ISL_TURN(0) ISL_TURN(1) ISL_TURN(2) ISL_TURN(3)
 #define ISL_TERMS                                                                              \
   const float p0 = dterm<METRIC>(q.x, x.x), p1 = dterm<METRIC>(q.y, x.y),                      \
               p2 = dterm<METRIC>(q.z, x.z), p3 = dterm<METRIC>(q.w, x.w);                      \
@@ -363,7 +389,7 @@ __device__ __forceinline__ float direct_group(const float* __restrict__ emb, uin
     x##k = *reinterpret_cast<const v4f*>(rp + 16u * (base + RING + (k)));         \
     ISL_QNEXT(k)                                                                  \
     ISL_PIN                                                                       \
-    ISL_QUARTER(ISL_ADD, 0) ISL_QUARTER(ISL_ADD, 1) ISL_QUARTER(ISL_ADD, 2) ISL_QUARTER(ISL_ADD, 3) \
+    ISL_ALL_TURNS                                                                 \
   }
 #define ISL_STEP(k)                                                               \
   {                                                                               \
@@ -373,7 +399,7 @@ __device__ __forceinline__ float direct_group(const float* __restrict__ emb, uin
     ISL_PIN                                                                       \
     ISL_QNEXT(k)                                                                  \
     ISL_PIN                                                                       \
-    ISL_QUARTER(ISL_ADD, 0) ISL_QUARTER(ISL_ADD, 1) ISL_QUARTER(ISL_ADD, 2) ISL_QUARTER(ISL_ADD, 3) \
+    ISL_ALL_TURNS                                                                 \
   }
     ISL_RING(ISL_DECLX)
     uint32_t base = 0;
@@ -405,16 +431,17 @@ __device__ __forceinline__ float direct_group(const float* __restrict__ emb, uin
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);                                     \
     if (e0 + s4 < ((d + 3u) & ~3u)) q = *reinterpret_cast<const float4*>(qp + e0); \
     ISL_TERMS                                                                       \
-    ISL_QUARTER(ISL_ADD_G, 0) ISL_QUARTER(ISL_ADD_G, 1) ISL_QUARTER(ISL_ADD_G, 2) ISL_QUARTER(ISL_ADD_G, 3) \
+    ISL_TURN_G(0) ISL_TURN_G(1) ISL_TURN_G(2) ISL_TURN_G(3)                         \
   }
       ISL_RING(ISL_ISSUE_C)
       ISL_RING(ISL_STEP_G)
 #undef ISL_ISSUE_C
 #undef ISL_STEP_G
     }
-#undef ISL_ADD
-#undef ISL_ADD_G
-#undef ISL_QUARTER
+#undef ISL_TURN
+#undef ISL_ADD_G1
+#undef ISL_TURN_G
+#undef ISL_ALL_TURNS
 #undef ISL_TERMS
 #undef ISL_DECLX
 #undef ISL_ISSUE
@@ -424,10 +451,136 @@ __device__ __forceinline__ float direct_group(const float* __restrict__ emb, uin
 #undef ISL_STEP_RELOAD
 #undef ISL_STEP
   }
+  a0 = quad_bcast<3>(a0);  // the sums end their round in lane 3
+  a1 = quad_bcast<3>(a1);
   if (METRIC == METRIC_COSINE_PRE) a1 = __shfl(row_aux, (int)((g0 + r) & 63u));
   return dfinish<METRIC>(a0, a1, q_norm);
 }
 #undef ISL_RING
+
+// NG groups of 16 rows at once: lane (r, s) of quad r runs the chains of rows g0 + r, g0 + 16 + r, ...
+// side by side.  Nothing changes in a row's arithmetic (same operands, same order: same bits) or in
+// the number of instructions per row; what changes is the latency of a hop.  One chain keeps a SIMD
+// busy for 88 of the 232 cycles a 16-element step takes (16 dependent v_add_f32_dpp of 14.5
+// cycles), so a wave that is alone on its SIMD -- the last batches of a run, a single batch in
+// flight -- evaluates the 30..50 new rows of a hop in one or two passes instead of three.  RN ring
+// slots per group (steps of 16 elements in flight per lane and row).
+template <int METRIC, int NG, int RN>
+__device__ __forceinline__ void direct_group_n(const float* __restrict__ emb, uint64_t stride, uint32_t d,
+                                               uint32_t rid, uint32_t g0, uint32_t Rg, const float* qs,
+                                               float q_norm, float row_aux, float (&dist)[NG]) {
+  const int lane = threadIdx.x;
+  const uint32_t r = (uint32_t)lane >> 2;
+  const uint32_t s4 = ((uint32_t)lane & 3u) * 4u;
+  const float* rp[NG];
+  float a0[NG], a1[NG];
+#pragma unroll
+  for (int m = 0; m < NG; ++m) {
+    // a quad without a row of its own in group m walks the group's first row again (the same
+    // cache lines as quad 0: no extra traffic) and its result is dropped
+    const uint32_t slot = 16u * m + r < Rg ? 16u * m + r : 16u * m;
+    const uint32_t row = (uint32_t)__shfl((int)rid, (int)((g0 + slot) & 63u));
+    rp[m] = emb + (uint64_t)row * stride + s4;
+    a0[m] = 0.0f;
+    a1[m] = 0.0f;
+  }
+  const float* qp = qs + s4;
+  const uint32_t nF = d >> 4;          // steps whose 16 elements all exist
+  const uint32_t nS = (d + 15u) >> 4;  // steps in total
+  v4f x[NG][RN];
+#define ISL_PIN __builtin_amdgcn_sched_barrier(0x40F);
+#define ISL_TURN_OF(ss)                                                                   \
+  _Pragma("unroll") for (int m = 0; m < NG; ++m) {                                         \
+    a0[m] = quad_prev(a0[m]);                                                               \
+    if constexpr (METRIC == ISL_METRIC_COSINE) a1[m] = quad_prev(a1[m]);                    \
+  }                                                                                         \
+  _Pragma("unroll") for (int c = 0; c < 4; ++c) _Pragma("unroll") for (int m = 0; m < NG; ++m) { \
+    if (!GUARD || e0 + 4u * (ss) + c < d) {                                                 \
+      a0[m] += pt[m][c];                                                                    \
+      if constexpr (METRIC == ISL_METRIC_COSINE) a1[m] += nt[m][c];                          \
+    }                                                                                       \
+  }
+  // one step: the products of every group, then (RELOAD) the slot's next load and the next query
+  // operand pinned ahead of the adds that hide their latency, then the chains side by side
+  auto step = [&](int k, auto reload, auto guard, uint32_t base, float4& qn) {
+    constexpr bool RELOAD = decltype(reload)::value, GUARD = decltype(guard)::value;
+    const uint32_t e0 = 16u * (base + k);
+    float4 q = qn;
+    if (GUARD) {
+      q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e0 + s4 < ((d + 3u) & ~3u)) q = *reinterpret_cast<const float4*>(qp + e0);
+    }
+    float pt[NG][4], nt[NG][4];
+#pragma unroll
+    for (int m = 0; m < NG; ++m) {
+      v4f xv = x[m][k];
+      asm volatile("" : "+v"(xv));
+      pt[m][0] = dterm<METRIC>(q.x, xv.x);
+      pt[m][1] = dterm<METRIC>(q.y, xv.y);
+      pt[m][2] = dterm<METRIC>(q.z, xv.z);
+      pt[m][3] = dterm<METRIC>(q.w, xv.w);
+      nt[m][0] = xv.x * xv.x;
+      nt[m][1] = xv.y * xv.y;
+      nt[m][2] = xv.z * xv.z;
+      nt[m][3] = xv.w * xv.w;
+    }
+    if (!GUARD) {
+      ISL_PIN
+      if (RELOAD) {
+#pragma unroll
+        for (int m = 0; m < NG; ++m) x[m][k] = *reinterpret_cast<const v4f*>(rp[m] + 16u * (base + RN + k));
+      }
+      const uint32_t sn = base + k + 1u < nS ? base + k + 1u : nS - 1u;
+      qn = *reinterpret_cast<const float4*>(qp + 16u * sn);
+      ISL_PIN
+    }
+    ISL_TURN_OF(0) ISL_TURN_OF(1) ISL_TURN_OF(2) ISL_TURN_OF(3)
+  };
+  auto steps = [&](auto reload, auto guard, uint32_t base, uint32_t rem, float4& qn) {
+#pragma unroll
+    for (int k = 0; k < RN; ++k)
+      if (!decltype(guard)::value || (uint32_t)k < rem) step(k, reload, guard, base, qn);
+  };
+  uint32_t base = 0;
+  float4 qn = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nF >= (uint32_t)RN) {
+#pragma unroll
+    for (int k = 0; k < RN; ++k)
+#pragma unroll
+      for (int m = 0; m < NG; ++m) x[m][k] = *reinterpret_cast<const v4f*>(rp[m] + 16u * k);
+    qn = *reinterpret_cast<const float4*>(qp);
+    ISL_PIN
+    while (base + 2u * RN <= nF) {
+      steps(std::true_type{}, std::false_type{}, base, 0u, qn);
+      base += RN;
+    }
+    steps(std::false_type{}, std::false_type{}, base, 0u, qn);
+    base += RN;
+  }
+  while (base < nS) {
+    // fewer than RN + 1 steps left (all of them when d < 16 RN): loads first, clamped to the last
+    // step so that they stay unconditional, then the guarded chains
+    const uint32_t rem = nS - base < (uint32_t)RN ? nS - base : (uint32_t)RN;
+    const uint32_t last = nS - 1u;
+#pragma unroll
+    for (int k = 0; k < RN; ++k) {
+      const uint32_t st = base + k < last ? base + k : last;
+#pragma unroll
+      for (int m = 0; m < NG; ++m) x[m][k] = *reinterpret_cast<const v4f*>(rp[m] + 16u * st);
+    }
+    steps(std::false_type{}, std::true_type{}, base, rem, qn);
+    base += rem;
+  }
+#undef ISL_PIN
+#undef ISL_TURN_OF
+#pragma unroll
+  for (int m = 0; m < NG; ++m) {
+    a0[m] = quad_bcast<3>(a0[m]);  // the sums end their round in lane 3
+    a1[m] = quad_bcast<3>(a1[m]);
+    if (METRIC == METRIC_COSINE_PRE) a1[m] = __shfl(row_aux, (int)((g0 + 16u * m + r) & 63u));
+    dist[m] = dfinish<METRIC>(a0[m], a1[m], q_norm);
+  }
+}
 
 // bf16 rows (ISL_DTYPE_BF16): the same quad layout with 8 elements per 16-byte load, so a step
 // covers 32 elements (lane s of the quad owns elements 32i + 8s .. + 7).  Every bf16 value is
@@ -487,11 +640,17 @@ __device__ __forceinline__ float direct_group_bf16(const uint16_t* __restrict__ 
     const uint16_t* rp = emb + (uint64_t)row * stride + s8;
     const uint32_t nF = d >> 5;
     const uint32_t nS = (d + 31u) >> 5;
-#define ISL_ADD(ss, c)                                                           \
-  a0 += quad_bcast<ss>(p##c);                                                     \
-  if constexpr (METRIC == ISL_METRIC_COSINE) a1 += quad_bcast<ss>(n##c);
-#define ISL_ADD_G(ss, c) if (e0 + 8 * (ss) + (c) < d) { ISL_ADD(ss, c) }
-#define ISL_OCT(A, ss) A(ss, 0) A(ss, 1) A(ss, 2) A(ss, 3) A(ss, 4) A(ss, 5) A(ss, 6) A(ss, 7)
+#define ISL_TURN(ss)                                                                          \
+  a0 = quad_prev(a0) + p0; a0 += p1; a0 += p2; a0 += p3; a0 += p4; a0 += p5; a0 += p6; a0 += p7; \
+  if constexpr (METRIC == ISL_METRIC_COSINE) {                                                 \
+    a1 = quad_prev(a1) + n0; a1 += n1; a1 += n2; a1 += n3; a1 += n4; a1 += n5; a1 += n6; a1 += n7; \
+  }
+#define ISL_ADD_G1(ss, c) if (e0 + 8 * (ss) + (c) < d) { a0 += p##c; if constexpr (METRIC == ISL_METRIC_COSINE) a1 += n##c; }
+#define ISL_TURN_G(ss)                                                                        \
+  a0 = quad_prev(a0);                                                                          \
+  if constexpr (METRIC == ISL_METRIC_COSINE) a1 = quad_prev(a1);                               \
+  ISL_ADD_G1(ss, 0) ISL_ADD_G1(ss, 1) ISL_ADD_G1(ss, 2) ISL_ADD_G1(ss, 3)                      \
+  ISL_ADD_G1(ss, 4) ISL_ADD_G1(ss, 5) ISL_ADD_G1(ss, 6) ISL_ADD_G1(ss, 7)
 #define ISL_WIDEN                                                                               \
   const float w0 = __uint_as_float(xv.x << 16), w1 = __uint_as_float(xv.x & 0xFFFF0000u),      \
               w2 = __uint_as_float(xv.y << 16), w3 = __uint_as_float(xv.y & 0xFFFF0000u),      \
@@ -516,7 +675,7 @@ __device__ __forceinline__ float direct_group_bf16(const uint16_t* __restrict__ 
       const uint32_t sn_ = base + (k) + 1u < nS ? base + (k) + 1u : nS - 1u;      \
       qn.load(qs, s8 + 32u * sn_);                                                \
     }
-#define ISL_ALL_ADDS ISL_OCT(ISL_ADD, 0) ISL_OCT(ISL_ADD, 1) ISL_OCT(ISL_ADD, 2) ISL_OCT(ISL_ADD, 3)
+#define ISL_ALL_ADDS ISL_TURN(0) ISL_TURN(1) ISL_TURN(2) ISL_TURN(3)
 #define ISL_STEP_RELOAD(k)                                                        \
   {                                                                               \
     ISL_TAKE(k)                                                                   \
@@ -571,16 +730,16 @@ __device__ __forceinline__ float direct_group_bf16(const uint16_t* __restrict__ 
     const float4 qa = qg_.lo(), qb = qg_.hi();                                      \
     ISL_WIDEN                                                                       \
     ISL_TERMS                                                                       \
-    ISL_OCT(ISL_ADD_G, 0) ISL_OCT(ISL_ADD_G, 1) ISL_OCT(ISL_ADD_G, 2) ISL_OCT(ISL_ADD_G, 3) \
+    ISL_TURN_G(0) ISL_TURN_G(1) ISL_TURN_G(2) ISL_TURN_G(3)                         \
   }
       ISL_RING(ISL_ISSUE_C)
       ISL_RING(ISL_STEP_G)
 #undef ISL_ISSUE_C
 #undef ISL_STEP_G
     }
-#undef ISL_ADD
-#undef ISL_ADD_G
-#undef ISL_OCT
+#undef ISL_TURN
+#undef ISL_ADD_G1
+#undef ISL_TURN_G
 #undef ISL_WIDEN
 #undef ISL_TERMS
 #undef ISL_DECLX
@@ -592,6 +751,8 @@ __device__ __forceinline__ float direct_group_bf16(const uint16_t* __restrict__ 
 #undef ISL_STEP_RELOAD
 #undef ISL_STEP
   }
+  a0 = quad_bcast<3>(a0);  // the sums end their round in lane 3
+  a1 = quad_bcast<3>(a1);
   if (METRIC == METRIC_COSINE_PRE) a1 = __shfl(row_aux, (int)((g0 + r) & 63u));
   return dfinish<METRIC>(a0, a1, q_norm);
 }
@@ -599,13 +760,29 @@ __device__ __forceinline__ float direct_group_bf16(const uint16_t* __restrict__ 
 
 // Tile-free counterpart of wave_distances: lane j < R receives the distance of row rid(j).
 // ROWT = float or uint16_t (bf16 bits).
-template <int METRIC, typename ROWT = float, bool QH = false>
+// NGMAX = 2 (float32 rows only): two groups at a time while more than 16 rows are left (direct_group_n).
+template <int METRIC, typename ROWT = float, bool QH = false, int NGMAX = 1>
 __device__ __forceinline__ float direct_distances(const ROWT* __restrict__ emb, uint64_t stride,
                                                   uint32_t d, uint32_t rid, uint32_t R,
                                                   const float* qs, float q_norm, float row_aux = 0.0f) {
   const int lane = threadIdx.x;
   float result = 0.0f;
   for (uint32_t g0 = 0; g0 < R; g0 += GROUP) {
+    if constexpr (NGMAX >= 2 && sizeof(ROWT) == 4) {
+      if (R - g0 > (uint32_t)GROUP) {
+        const uint32_t Rg = R - g0 < 2u * GROUP ? R - g0 : 2u * GROUP;
+        float dm[2];
+        direct_group_n<METRIC, 2, 6>(reinterpret_cast<const float*>(emb), stride, d, rid, g0, Rg, qs, q_norm, row_aux, dm);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const uint32_t lo = g0 + 16u * m, hi = g0 + Rg;
+          const float moved = __shfl(dm[m], (4 * (lane - (int)lo)) & 63);
+          if ((uint32_t)lane >= lo && (uint32_t)lane < lo + 16u && (uint32_t)lane < hi) result = moved;
+        }
+        g0 += GROUP;  // (two groups done: the loop adds the other 16)
+        continue;
+      }
+    }
     const uint32_t Rg = R - g0 < (uint32_t)GROUP ? R - g0 : (uint32_t)GROUP;
     float dist;
     if constexpr (sizeof(ROWT) == 2)

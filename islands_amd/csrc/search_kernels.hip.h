@@ -130,25 +130,27 @@ __device__ __forceinline__ bool odd_distance(float d) {
   return d != d || __float_as_uint(d) == 0x80000000u;
 }
 
+// (every member is force-inlined: one call left out of line makes `this` escape and the whole set --
+// kd, id, len -- lives in scratch memory instead of registers)
 template <int S>
 struct RSet {
   uint32_t kd[S];
   uint32_t id[S];
   uint32_t len;  // wave-uniform
 
-  __device__ void init() {
+  __device__ __forceinline__ void init() {
 #pragma unroll
     for (int s = 0; s < S; ++s) { kd[s] = KEY_MAX; id[s] = KEY_MAX; }
     len = 0;
   }
-  __device__ uint32_t key_at(uint32_t e) const {
+  __device__ __forceinline__ uint32_t key_at(uint32_t e) const {
     uint32_t r = 0;
 #pragma unroll
     for (int s = 0; s < S; ++s)
       if ((int)(e >> 6) == s) r = rl_u(kd[s], e & 63);
     return r;
   }
-  __device__ uint32_t id_at(uint32_t e) const {
+  __device__ __forceinline__ uint32_t id_at(uint32_t e) const {
     uint32_t r = 0;
 #pragma unroll
     for (int s = 0; s < S; ++s)
@@ -156,7 +158,7 @@ struct RSet {
     return r;
   }
   // first entry not yet expanded, or 0xFFFFFFFF
-  __device__ uint32_t first_unexpanded() const {
+  __device__ __forceinline__ uint32_t first_unexpanded() const {
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       uint64_t m = ballot(!(id[s] & FLAG_EXP));
@@ -164,7 +166,7 @@ struct RSet {
     }
     return 0xFFFFFFFFu;
   }
-  __device__ void mark_expanded(uint32_t e) {
+  __device__ __forceinline__ void mark_expanded(uint32_t e) {
     const int lane = threadIdx.x;
 #pragma unroll
     for (int s = 0; s < S; ++s)
@@ -590,8 +592,10 @@ __global__ __launch_bounds__(64) void classify_queries_kernel(SearchParams p) {
 // 64 at a time in CSR order -- the same sequential rule, run over two slices.
 // RESUME = searches over the recompute provider: a query that meets an absent row parks its whole
 // state and is taken up again, in the hop it stopped at, once the provider has encoded the row.
+// (amdgpu_waves_per_eu(3): the LDS footprint admits 12 waves per CU; 168 VGPRs keep three per SIMD,
+// 169 round up to 176 and leave two)
 template <int S, int METRIC_API, typename ROWT, bool WIDE, bool RESUME = false, bool QH = false>
-__global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void leann_search_fast(SearchParams p) {
   static_assert(!QH || (sizeof(ROWT) == 2 && !RESUME), "the bf16 query operand goes with bf16 rows");
   constexpr uint32_t kMaxDeg = WIDE ? 128u : 64u;
   // parked state of one query, in words: 16 scalars, tie list, the hop's unvisited ids (2 x 64),
@@ -878,7 +882,9 @@ __global__ __launch_bounds__(64) void leann_search_fast(SearchParams p) {
       ngroups += (keep + 15) / 16;
       const uint32_t rix = row_index(p, uid, (uint32_t)lane < keep);
       float r_aux = (METRIC == METRIC_COSINE_PRE && (uint32_t)lane < keep) ? p.norm2[rix] : 0.0f;
-      float nd = direct_distances<METRIC, ROWT, QH>(emb, p.stride, p.d, rix, keep, qs, q_norm, r_aux);
+      // (two groups of rows side by side where the registers allow: device_common.hip.h, direct_group_n)
+      constexpr int NGMAX = (S <= 2 && !WIDE && !RESUME && sizeof(ROWT) == 4) ? 2 : 1;
+      float nd = direct_distances<METRIC, ROWT, QH, NGMAX>(emb, p.stride, p.d, rix, keep, qs, q_norm, r_aux);
       ISL_MARK(tp2)  // row fetch + distances
 
       // leann.rs:953-970 in CSR order; worst = results.peek().  NaN / -0.0 distances have no
