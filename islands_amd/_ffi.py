@@ -15,7 +15,8 @@ import os
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libislands_amd.so")
+# ISL_AMD_LIB: another build of the same library (A/B measurements of two builds on one card)
+LIB_PATH = os.environ.get("ISL_AMD_LIB") or os.path.join(_HERE, "lib", "libislands_amd.so")
 
 u64, u32, i32, f32 = C.c_uint64, C.c_uint32, C.c_int32, C.c_float
 P = C.POINTER

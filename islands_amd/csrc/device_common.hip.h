@@ -1,12 +1,10 @@
 // Device helpers shared by the kernels of libislands_amd.so: wave-level utilities and the
 // exact-order distance routine (the four lanes of a quad own one row: each multiplies four of
-// every 16 elements, all four run the reference's strictly sequential f32 add chain and pull
-// the products out of each other with DPP quad_perm; rows are staged through an LDS tile with
-// coalesced 16-byte loads).
+// every 16 elements, and the reference's strictly sequential f32 sum travels round the quad --
+// see "The quad chain" below; rows are staged through an LDS tile with coalesced 16-byte loads,
+// or fetched straight into a register ring).
 // Translation units including this file must be built with -ffp-contract=off.
 #pragma once
-#include <type_traits>
-#include <utility>
 
 #include "common.hpp"
 
@@ -458,130 +456,6 @@ __device__ __forceinline__ float direct_group(const float* __restrict__ emb, uin
 }
 #undef ISL_RING
 
-// NG groups of 16 rows at once: lane (r, s) of quad r runs the chains of rows g0 + r, g0 + 16 + r, ...
-// side by side.  Nothing changes in a row's arithmetic (same operands, same order: same bits) or in
-// the number of instructions per row; what changes is the latency of a hop.  One chain keeps a SIMD
-// busy for 88 of the 232 cycles a 16-element step takes (16 dependent v_add_f32_dpp of 14.5
-// cycles), so a wave that is alone on its SIMD -- the last batches of a run, a single batch in
-// flight -- evaluates the 30..50 new rows of a hop in one or two passes instead of three.  RN ring
-// slots per group (steps of 16 elements in flight per lane and row).
-template <int METRIC, int NG, int RN>
-__device__ __forceinline__ void direct_group_n(const float* __restrict__ emb, uint64_t stride, uint32_t d,
-                                               uint32_t rid, uint32_t g0, uint32_t Rg, const float* qs,
-                                               float q_norm, float row_aux, float (&dist)[NG]) {
-  const int lane = threadIdx.x;
-  const uint32_t r = (uint32_t)lane >> 2;
-  const uint32_t s4 = ((uint32_t)lane & 3u) * 4u;
-  const float* rp[NG];
-  float a0[NG], a1[NG];
-#pragma unroll
-  for (int m = 0; m < NG; ++m) {
-    // a quad without a row of its own in group m walks the group's first row again (the same
-    // cache lines as quad 0: no extra traffic) and its result is dropped
-    const uint32_t slot = 16u * m + r < Rg ? 16u * m + r : 16u * m;
-    const uint32_t row = (uint32_t)__shfl((int)rid, (int)((g0 + slot) & 63u));
-    rp[m] = emb + (uint64_t)row * stride + s4;
-    a0[m] = 0.0f;
-    a1[m] = 0.0f;
-  }
-  const float* qp = qs + s4;
-  const uint32_t nF = d >> 4;          // steps whose 16 elements all exist
-  const uint32_t nS = (d + 15u) >> 4;  // steps in total
-  v4f x[NG][RN];
-#define ISL_PIN __builtin_amdgcn_sched_barrier(0x40F);
-#define ISL_TURN_OF(ss)                                                                   \
-  _Pragma("unroll") for (int m = 0; m < NG; ++m) {                                         \
-    a0[m] = quad_prev(a0[m]);                                                               \
-    if constexpr (METRIC == ISL_METRIC_COSINE) a1[m] = quad_prev(a1[m]);                    \
-  }                                                                                         \
-  _Pragma("unroll") for (int c = 0; c < 4; ++c) _Pragma("unroll") for (int m = 0; m < NG; ++m) { \
-    if (!GUARD || e0 + 4u * (ss) + c < d) {                                                 \
-      a0[m] += pt[m][c];                                                                    \
-      if constexpr (METRIC == ISL_METRIC_COSINE) a1[m] += nt[m][c];                          \
-    }                                                                                       \
-  }
-  // one step: the products of every group, then (RELOAD) the slot's next load and the next query
-  // operand pinned ahead of the adds that hide their latency, then the chains side by side
-  auto step = [&](int k, auto reload, auto guard, uint32_t base, float4& qn) {
-    constexpr bool RELOAD = decltype(reload)::value, GUARD = decltype(guard)::value;
-    const uint32_t e0 = 16u * (base + k);
-    float4 q = qn;
-    if (GUARD) {
-      q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e0 + s4 < ((d + 3u) & ~3u)) q = *reinterpret_cast<const float4*>(qp + e0);
-    }
-    float pt[NG][4], nt[NG][4];
-#pragma unroll
-    for (int m = 0; m < NG; ++m) {
-      v4f xv = x[m][k];
-      asm volatile("" : "+v"(xv));
-      pt[m][0] = dterm<METRIC>(q.x, xv.x);
-      pt[m][1] = dterm<METRIC>(q.y, xv.y);
-      pt[m][2] = dterm<METRIC>(q.z, xv.z);
-      pt[m][3] = dterm<METRIC>(q.w, xv.w);
-      nt[m][0] = xv.x * xv.x;
-      nt[m][1] = xv.y * xv.y;
-      nt[m][2] = xv.z * xv.z;
-      nt[m][3] = xv.w * xv.w;
-    }
-    if (!GUARD) {
-      ISL_PIN
-      if (RELOAD) {
-#pragma unroll
-        for (int m = 0; m < NG; ++m) x[m][k] = *reinterpret_cast<const v4f*>(rp[m] + 16u * (base + RN + k));
-      }
-      const uint32_t sn = base + k + 1u < nS ? base + k + 1u : nS - 1u;
-      qn = *reinterpret_cast<const float4*>(qp + 16u * sn);
-      ISL_PIN
-    }
-    ISL_TURN_OF(0) ISL_TURN_OF(1) ISL_TURN_OF(2) ISL_TURN_OF(3)
-  };
-  auto steps = [&](auto reload, auto guard, uint32_t base, uint32_t rem, float4& qn) {
-#pragma unroll
-    for (int k = 0; k < RN; ++k)
-      if (!decltype(guard)::value || (uint32_t)k < rem) step(k, reload, guard, base, qn);
-  };
-  uint32_t base = 0;
-  float4 qn = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (nF >= (uint32_t)RN) {
-#pragma unroll
-    for (int k = 0; k < RN; ++k)
-#pragma unroll
-      for (int m = 0; m < NG; ++m) x[m][k] = *reinterpret_cast<const v4f*>(rp[m] + 16u * k);
-    qn = *reinterpret_cast<const float4*>(qp);
-    ISL_PIN
-    while (base + 2u * RN <= nF) {
-      steps(std::true_type{}, std::false_type{}, base, 0u, qn);
-      base += RN;
-    }
-    steps(std::false_type{}, std::false_type{}, base, 0u, qn);
-    base += RN;
-  }
-  while (base < nS) {
-    // fewer than RN + 1 steps left (all of them when d < 16 RN): loads first, clamped to the last
-    // step so that they stay unconditional, then the guarded chains
-    const uint32_t rem = nS - base < (uint32_t)RN ? nS - base : (uint32_t)RN;
-    const uint32_t last = nS - 1u;
-#pragma unroll
-    for (int k = 0; k < RN; ++k) {
-      const uint32_t st = base + k < last ? base + k : last;
-#pragma unroll
-      for (int m = 0; m < NG; ++m) x[m][k] = *reinterpret_cast<const v4f*>(rp[m] + 16u * st);
-    }
-    steps(std::false_type{}, std::true_type{}, base, rem, qn);
-    base += rem;
-  }
-#undef ISL_PIN
-#undef ISL_TURN_OF
-#pragma unroll
-  for (int m = 0; m < NG; ++m) {
-    a0[m] = quad_bcast<3>(a0[m]);  // the sums end their round in lane 3
-    a1[m] = quad_bcast<3>(a1[m]);
-    if (METRIC == METRIC_COSINE_PRE) a1[m] = __shfl(row_aux, (int)((g0 + 16u * m + r) & 63u));
-    dist[m] = dfinish<METRIC>(a0[m], a1[m], q_norm);
-  }
-}
-
 // bf16 rows (ISL_DTYPE_BF16): the same quad layout with 8 elements per 16-byte load, so a step
 // covers 32 elements (lane s of the quad owns elements 32i + 8s .. + 7).  Every bf16 value is
 // exactly representable in f32 and widened before use: the arithmetic is the f32 chain of the
@@ -760,29 +634,13 @@ __device__ __forceinline__ float direct_group_bf16(const uint16_t* __restrict__ 
 
 // Tile-free counterpart of wave_distances: lane j < R receives the distance of row rid(j).
 // ROWT = float or uint16_t (bf16 bits).
-// NGMAX = 2 (float32 rows only): two groups at a time while more than 16 rows are left (direct_group_n).
-template <int METRIC, typename ROWT = float, bool QH = false, int NGMAX = 1>
+template <int METRIC, typename ROWT = float, bool QH = false>
 __device__ __forceinline__ float direct_distances(const ROWT* __restrict__ emb, uint64_t stride,
                                                   uint32_t d, uint32_t rid, uint32_t R,
                                                   const float* qs, float q_norm, float row_aux = 0.0f) {
   const int lane = threadIdx.x;
   float result = 0.0f;
   for (uint32_t g0 = 0; g0 < R; g0 += GROUP) {
-    if constexpr (NGMAX >= 2 && sizeof(ROWT) == 4) {
-      if (R - g0 > (uint32_t)GROUP) {
-        const uint32_t Rg = R - g0 < 2u * GROUP ? R - g0 : 2u * GROUP;
-        float dm[2];
-        direct_group_n<METRIC, 2, 6>(reinterpret_cast<const float*>(emb), stride, d, rid, g0, Rg, qs, q_norm, row_aux, dm);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const uint32_t lo = g0 + 16u * m, hi = g0 + Rg;
-          const float moved = __shfl(dm[m], (4 * (lane - (int)lo)) & 63);
-          if ((uint32_t)lane >= lo && (uint32_t)lane < lo + 16u && (uint32_t)lane < hi) result = moved;
-        }
-        g0 += GROUP;  // (two groups done: the loop adds the other 16)
-        continue;
-      }
-    }
     const uint32_t Rg = R - g0 < (uint32_t)GROUP ? R - g0 : (uint32_t)GROUP;
     float dist;
     if constexpr (sizeof(ROWT) == 2)

@@ -882,9 +882,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void le
       ngroups += (keep + 15) / 16;
       const uint32_t rix = row_index(p, uid, (uint32_t)lane < keep);
       float r_aux = (METRIC == METRIC_COSINE_PRE && (uint32_t)lane < keep) ? p.norm2[rix] : 0.0f;
-      // (two groups of rows side by side where the registers allow: device_common.hip.h, direct_group_n)
-      constexpr int NGMAX = (S <= 2 && !WIDE && !RESUME && sizeof(ROWT) == 4) ? 2 : 1;
-      float nd = direct_distances<METRIC, ROWT, QH, NGMAX>(emb, p.stride, p.d, rix, keep, qs, q_norm, r_aux);
+      float nd = direct_distances<METRIC, ROWT, QH>(emb, p.stride, p.d, rix, keep, qs, q_norm, r_aux);
       ISL_MARK(tp2)  // row fetch + distances
 
       // leann.rs:953-970 in CSR order; worst = results.peek().  NaN / -0.0 distances have no
