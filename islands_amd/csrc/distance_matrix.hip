@@ -15,31 +15,59 @@ namespace {
 
 using namespace isl_gemm;
 
-// sum of squares of every row (one wave per row)
-__global__ __launch_bounds__(64) void sumsq_rows_kernel(const float* __restrict__ x, uint64_t n, uint32_t d,
-                                                        uint64_t stride, float* __restrict__ out) {
-  const uint64_t row = blockIdx.x;
+// sum of squares of every row (one wave per row, 16 bytes per lane and load when the rows allow it)
+__global__ __launch_bounds__(256) void sumsq_rows_kernel(const float* __restrict__ x, uint64_t n, uint32_t d,
+                                                         uint64_t stride, float* __restrict__ out) {
+  const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
   if (row >= n) return;
+  const float* rp = x + row * stride;
   float s = 0.0f;
-  for (uint32_t j = threadIdx.x; j < d; j += 64) { float v = x[row * stride + j]; s += v * v; }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-  if (threadIdx.x == 0) out[row] = s;
-}
-
-// the same for bf16 rows (their exact f32 images are squared)
-__global__ __launch_bounds__(64) void sumsq_rows_bf16_kernel(const uint16_t* __restrict__ x, uint64_t n, uint32_t d,
-                                                             float* __restrict__ out) {
-  const uint64_t row = blockIdx.x;
-  if (row >= n) return;
-  float s = 0.0f;
-  for (uint32_t j = threadIdx.x; j < d; j += 64) {
-    const float v = __uint_as_float((uint32_t)x[row * d + j] << 16);
-    s += v * v;
+  if ((d & 3u) == 0 && (stride & 3u) == 0 && ((uintptr_t)x & 15u) == 0) {
+    for (uint32_t j = lane * 4; j < d; j += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(rp + j);
+      s += v.x * v.x;
+      s += v.y * v.y;
+      s += v.z * v.z;
+      s += v.w * v.w;
+    }
+  } else {
+    for (uint32_t j = lane; j < d; j += 64) { float v = rp[j]; s += v * v; }
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-  if (threadIdx.x == 0) out[row] = s;
+  if (lane == 0) out[row] = s;
+}
+
+// the same for bf16 rows (their exact f32 images are squared): one wave per row, 16 bytes per lane
+// and load when the row allows it
+__global__ __launch_bounds__(256) void sumsq_rows_bf16_kernel(const uint16_t* __restrict__ x, uint64_t n, uint32_t d,
+                                                              float* __restrict__ out) {
+  const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const uint16_t* rp = x + row * d;
+  float s = 0.0f;
+  if ((d & 7u) == 0 && ((uintptr_t)x & 15u) == 0) {
+    for (uint32_t j = lane * 8; j < d; j += 512) {
+      const uint4 w = *reinterpret_cast<const uint4*>(rp + j);
+      const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float lo = __uint_as_float(ws[u] << 16), hi = __uint_as_float(ws[u] & 0xFFFF0000u);
+        s += lo * lo;
+        s += hi * hi;
+      }
+    }
+  } else {
+    for (uint32_t j = lane; j < d; j += 64) {
+      const float v = __uint_as_float((uint32_t)rp[j] << 16);
+      s += v * v;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) out[row] = s;
 }
 
 // Keeps the k smallest (distance, id) of every query across column chunks: one wave per query,
@@ -182,8 +210,10 @@ isl_status isl_distance_matrix_bf16(int32_t metric, const uint16_t* queries, uin
   float* qn = (float*)s.alloc(nq * 4);
   float* rn = (float*)s.alloc(n * 4);
   if (!qn || !rn) return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed");
-  hipLaunchKernelGGL(sumsq_rows_bf16_kernel, dim3((uint32_t)nq), dim3(64), 0, st, dq, nq, (uint32_t)d, qn);
-  hipLaunchKernelGGL(sumsq_rows_bf16_kernel, dim3((uint32_t)n), dim3(64), 0, st, dr, n, (uint32_t)d, rn);
+  if (metric != ISL_METRIC_DOT) {  // (the dot epilogue reads no norms)
+    hipLaunchKernelGGL(sumsq_rows_bf16_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, dq, nq, (uint32_t)d, qn);
+    hipLaunchKernelGGL(sumsq_rows_bf16_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, dr, n, (uint32_t)d, rn);
+  }
   ISL_TRY(launch_distance_gemm_bf16(metric, dq, dr, qn, rn, dout, nq, n, d, n, st));
   if (mem == ISL_MEM_HOST) ISL_HIP(hipMemcpyAsync(out, dout, nq * n * 4, hipMemcpyDeviceToHost, st));
   ISL_HIP(hipStreamSynchronize(st));
@@ -208,8 +238,8 @@ isl_status isl_distance_matrix(int32_t metric, const float* queries, uint64_t nq
   float* rn = (float*)s.alloc(n * 4);
   float* dout = mem == ISL_MEM_DEVICE ? out : (float*)s.alloc(nq * n * 4);
   if (!qn || !rn || !dout) return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed");
-  hipLaunchKernelGGL(sumsq_rows_kernel, dim3((uint32_t)nq), dim3(64), 0, st, dq, nq, (uint32_t)d, ldq, qn);
-  hipLaunchKernelGGL(sumsq_rows_kernel, dim3((uint32_t)n), dim3(64), 0, st, dr, n, (uint32_t)d, ldr, rn);
+  hipLaunchKernelGGL(sumsq_rows_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, dq, nq, (uint32_t)d, ldq, qn);
+  hipLaunchKernelGGL(sumsq_rows_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, dr, n, (uint32_t)d, ldr, rn);
   ISL_TRY(launch_distance_gemm(metric, dq, dr, qn, rn, dout, nq, n, ldq, st));
   if (mem == ISL_MEM_HOST) ISL_HIP(hipMemcpyAsync(out, dout, nq * n * 4, hipMemcpyDeviceToHost, st));
   ISL_HIP(hipStreamSynchronize(st));
@@ -244,10 +274,10 @@ isl_status isl_bruteforce_topk(int32_t metric, const float* queries, uint64_t nq
     float* rn = (float*)s.alloc(n * 4);
     float* blk = (float*)s.alloc(nq * chunk * 4);
     if (!qn || !rn || !blk) return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed");
-    hipLaunchKernelGGL(sumsq_rows_kernel, dim3((uint32_t)nq), dim3(64), 0, st, dq, nq, (uint32_t)d, ldq, qn);
-    for (uint64_t r0 = 0; r0 < n; r0 += 0x7FFFFFFFull)  // grid.x limit
-      hipLaunchKernelGGL(sumsq_rows_kernel, dim3((uint32_t)std::min<uint64_t>(n - r0, 0x7FFFFFFFull)), dim3(64), 0,
-                         st, dr + r0 * ldr, n - r0, (uint32_t)d, ldr, rn + r0);
+    hipLaunchKernelGGL(sumsq_rows_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, dq, nq, (uint32_t)d, ldq, qn);
+    for (uint64_t r0 = 0; r0 < n; r0 += 0x7FFFFFFCull)  // grid.x limit (four rows per workgroup)
+      hipLaunchKernelGGL(sumsq_rows_kernel, dim3((uint32_t)((std::min<uint64_t>(n - r0, 0x7FFFFFFCull) + 3) / 4)), dim3(256), 0,
+                         st, dr + r0 * ldr, std::min<uint64_t>(n - r0, 0x7FFFFFFCull), (uint32_t)d, ldr, rn + r0);
     const size_t lds = ((kk * 4 + 7) & ~7ull) + kk * 8;
     for (uint64_t c0 = 0; c0 < n; c0 += chunk) {
       const uint64_t cols = std::min(chunk, n - c0);

@@ -165,13 +165,17 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const void* __restrict__ Av,
 //   <2,2,2,2>: 128 x 128, 256 threads, 64 KiB LDS, two workgroups per CU;
 //   <2,4,4,2>: 256 x 256, 512 threads, 128 KiB LDS, one per CU -- 128 x 64 per wave reads 6 operand
 //   fragments per 8 MFMAs instead of 4 per 4, and a slab byte feeds twice the flops.
-template <int ACT, bool RES, bool C16, int WM, int WN, int MF, int NF>
+// EXP (tools/microbench/gemm_bf16_exp.hip only): bit 0 = all waves issue their DMA pieces behind the barrier
+// (without it waves 4..7 issue theirs half a slab later than waves 0..3); bit 1 =
+// staggered start of the workgroups; bit 7 = s_memtime stamps of waves 0 and 4 of workgroup 300 -> dbg.
+template <int ACT, bool RES, bool C16, int WM, int WN, int MF, int NF, int EXP = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_bf16_dma(const __bf16* __restrict__ A,
                                                                  const __bf16* __restrict__ W,
                                                                  const float* __restrict__ bias,
                                                                  const float* __restrict__ R,
                                                                  void* __restrict__ Cv, uint32_t M, uint32_t N,
-                                                                 uint32_t K, uint32_t ntn, uint64_t ldc) {
+                                                                 uint32_t K, uint32_t ntn, uint64_t ldc,
+                                                                 uint64_t* dbg = nullptr) {
   constexpr uint32_t TM = 32 * MF * WM, TN = 32 * NF * WN, NW = WM * WN;
   constexpr uint32_t ABYTES = TM * HBK * 2, WBYTES = TN * HBK * 2, BUF = ABYTES + WBYTES;
   constexpr int NIA = TM * 8 / (64 * NW), NIW = TN * 8 / (64 * NW);  // DMA instructions per wave and slab
@@ -226,15 +230,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_bf16_dma(const __bf16* _
   };
   const uint32_t kh = lane >> 5, c32 = lane & 31;
   const uint32_t nk = K / HBK;
+  if ((EXP & 2) && gridDim.x > 256) {
+    const uint32_t naps = (blockIdx.x * 37u) % 12u;
+    for (uint32_t z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(127);
+  }
+  // the two waves of a SIMD (w and w + 4) do not queue on the texture-address unit together: the
+  // second issues its DMA pieces half a slab later (+2 % on 4096 x 65536 x 4096; EXP bit 0 turns it off)
+  const bool late = !(EXP & 1) && NW == 8 && wave >= NW / 2;
+  const bool stamp = (EXP & 128) && blockIdx.x == 300 && (wave & 3) == 0 && lane == 0;
+  uint64_t tacc[5] = {0, 0, 0, 0, 0};
   issue(0, 0);
   for (uint32_t kt = 0; kt < nk; ++kt) {
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (EXP & 128) t0 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of slab kt has landed
+    if (EXP & 128) t1 = __builtin_amdgcn_s_memtime();
     __syncthreads();  // everyone's share has; everyone is done reading the other buffer
-    if (kt + 1 < nk) issue((kt + 1) * HBK, (kt + 1) & 1);
+    if (EXP & 128) t2 = __builtin_amdgcn_s_memtime();
+    if (kt + 1 < nk && !late) issue((kt + 1) * HBK, (kt + 1) & 1);
+    if (EXP & 128) t3 = __builtin_amdgcn_s_memtime();
     const unsigned char* ab = lds + (kt & 1) * BUF;
     const unsigned char* wb = ab + ABYTES;
 #pragma unroll
     for (int ks = 0; ks < HBK / 16; ++ks) {
+      if (ks == HBK / 32 && late && kt + 1 < nk) issue((kt + 1) * HBK, (kt + 1) & 1);
       const uint32_t cl = 2 * ks + kh;  // logical 16-byte chunk of the row
       bf16x8 b[NF];
 #pragma unroll
@@ -250,6 +269,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_bf16_dma(const __bf16* _
         for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[i][j], 0, 0, 0);
       }
     }
+    if (EXP & 128) {
+      const uint64_t t4 = __builtin_amdgcn_s_memtime();
+      if (kt >= 8 && kt < 56) { tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2; tacc[3] += t4 - t3; tacc[4] += 1; }
+    }
+  }
+  if ((EXP & 128) && stamp && dbg) {
+#pragma unroll
+    for (int z = 0; z < 5; ++z) dbg[(wave >> 2) * 8 + z] = tacc[z];
   }
 #pragma unroll
   for (int i = 0; i < MF; ++i)
@@ -269,13 +296,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_bf16_dma(const __bf16* _
           if (ACT == 2) v = gelu_tanh_f(v);
           if (RES) v += R[m * N + n];
         } else if (ACT == EPI_COSINE) {  // bias = |w_n|^2 per column, R = |a_m|^2 per row
-          const float norm = sqrtf(R[m] * bv);
-          v = norm == 0.0f ? 1.0f : 1.0f - v / norm;
+          v = epi_cosine(v, R[m], bv);
         } else if (ACT == EPI_DOT) {
           v = -v;
         } else if (ACT == EPI_EUCLIDEAN) {  // |a|^2 + |w|^2 - 2 a.w, clamped
-          v = R[m] + bv - 2.0f * v;
-          v = sqrtf(v > 0.0f ? v : 0.0f);
+          v = epi_euclidean(v, R[m], bv);
         }
         if constexpr (C16) Ch[m * N + n] = (__bf16)v;
         else C[(uint64_t)m * ldc + n] = v;
@@ -299,13 +324,13 @@ void launch_gemm_bf16_dma(const __bf16* A, const __bf16* W, const float* bias, c
     }();
     (void)once;
     hipLaunchKernelGGL(kern, dim3((uint32_t)big), dim3(512), lds, st, A, W, bias, R, C, (uint32_t)M, (uint32_t)N,
-                       (uint32_t)K, (uint32_t)((N + 255) / 256), ldc);
+                       (uint32_t)K, (uint32_t)((N + 255) / 256), ldc, (uint64_t*)nullptr);
   } else {
     const uint64_t ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     auto kern = gemm_tn_bf16_dma<ACT, RES, C16, 2, 2, 2, 2>;
     constexpr size_t lds = 2 * (BM + BN) * HBK * 2;
     hipLaunchKernelGGL(kern, dim3((uint32_t)(ntm * ntn)), dim3(256), lds, st, A, W, bias, R, C, (uint32_t)M,
-                       (uint32_t)N, (uint32_t)K, (uint32_t)ntn, ldc);
+                       (uint32_t)N, (uint32_t)K, (uint32_t)ntn, ldc, (uint64_t*)nullptr);
   }
 }
 
