@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const void* __restrict__ Av,
 //   <2,4,4,2>: 256 x 256, 512 threads, 128 KiB LDS, one per CU -- 128 x 64 per wave reads 6 operand
 //   fragments per 8 MFMAs instead of 4 per 4, and a slab byte feeds twice the flops.
 // EXP (tools/microbench/gemm_bf16_exp.hip only): bit 0 = all waves issue their DMA pieces behind the barrier
-// (without it waves 4..7 issue theirs half a slab later than waves 0..3); bit 1 =
+// (without it waves 4..7 issue theirs one k-step later than waves 0..3; bits 2-3: another k-step); bit 1 =
 // staggered start of the workgroups; bit 7 = s_memtime stamps of waves 0 and 4 of workgroup 300 -> dbg.
 template <int ACT, bool RES, bool C16, int WM, int WN, int MF, int NF, int EXP = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_bf16_dma(const __bf16* __restrict__ A,
@@ -235,7 +235,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_bf16_dma(const __bf16* _
     for (uint32_t z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(127);
   }
   // the two waves of a SIMD (w and w + 4) do not queue on the texture-address unit together: the
-  // second issues its DMA pieces half a slab later (+2 % on 4096 x 65536 x 4096; EXP bit 0 turns it off)
+  // second issues its DMA pieces one k-step (a quarter of the slab) later (+3 % on 4096 x 65536 x 4096;
+  // EXP bit 0 turns it off, bits 2-3 move it)
   const bool late = !(EXP & 1) && NW == 8 && wave >= NW / 2;
   const bool stamp = (EXP & 128) && blockIdx.x == 300 && (wave & 3) == 0 && lane == 0;
   uint64_t tacc[5] = {0, 0, 0, 0, 0};
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_bf16_dma(const __bf16* _
     const unsigned char* wb = ab + ABYTES;
 #pragma unroll
     for (int ks = 0; ks < HBK / 16; ++ks) {
-      if (ks == HBK / 32 && late && kt + 1 < nk) issue((kt + 1) * HBK, (kt + 1) & 1);
+      if (ks == (((EXP >> 2) & 3) ? ((EXP >> 2) & 3) : 1) && late && kt + 1 < nk) issue((kt + 1) * HBK, (kt + 1) & 1);
       const uint32_t cl = 2 * ks + kh;  // logical 16-byte chunk of the row
       bf16x8 b[NF];
 #pragma unroll

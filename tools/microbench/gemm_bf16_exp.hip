@@ -67,26 +67,30 @@ int main(int argc, char** argv) {
   }
   g_rn = rn;
   g_qn = qn;
-  for (int round = 0; round < 4; ++round) {
-    const float t0 = run<0>(A, W, C, M, N, K, 40, dbg);
-    const float t1 = run<1>(A, W, C2, M, N, K, 40, dbg);
-    const float t2 = run<2>(A, W, C2, M, N, K, 40, dbg);
-    const float t3 = run<3>(A, W, C2, M, N, K, 40, dbg);
-    const float tc = run<0, EPI_COSINE>(A, W, C2, M, N, K, 40, dbg);
-    const float tc1 = run<1, EPI_COSINE>(A, W, C2, M, N, K, 40, dbg);
-    printf("cosine epilogue: base %.3f ms %.1f TF | late-half %.3f ms %.1f TF\n", tc, fl / tc / 1e9, tc1, fl / tc1 / 1e9);
-    printf("M=%u N=%u K=%u  base %.3f ms %.1f TF | late-half %.3f ms %.1f TF | stagger-start %.3f ms %.1f TF | both %.3f ms %.1f TF\n", M, N, K,
+  for (int round = 0; round < 3; ++round) {
+    const float t0 = run<1>(A, W, C, M, N, K, 40, dbg);
+    const float t1 = run<8>(A, W, C2, M, N, K, 40, dbg);
+    const float t2 = run<0>(A, W, C2, M, N, K, 40, dbg);
+    const float t3 = run<12>(A, W, C2, M, N, K, 40, dbg);
+
+    printf("M=%u N=%u K=%u  all behind the barrier %.3f ms %.1f TF | waves 4..7 at k-step 2 %.3f ms %.1f TF | at 1 %.3f ms %.1f TF | at 3 %.3f ms %.1f TF\n", M, N, K,
            t0, fl / t0 / 1e9, t1, fl / t1 / 1e9, t2, fl / t2 / 1e9, t3, fl / t3 / 1e9);
   }
-  const float ts = run<128>(A, W, C2, M, N, K, 2, dbg);
-  uint64_t hd[16];
-  (void)hipMemcpy(hd, dbg, sizeof(hd), hipMemcpyDeviceToHost);
-  printf("stamped run %.3f ms; workgroup 300, mean cycles per slab (s_memtime ticks)\n", ts);
-  for (int w = 0; w < 2; ++w) {
-    const double n = hd[w * 8 + 4] ? (double)hd[w * 8 + 4] : 1.0;
-    printf("  wave %d: wait vmcnt %.0f | barrier %.0f | DMA issue %.0f | ds_read + MFMA issue %.0f | slabs %g\n", w * 4, hd[w * 8] / n,
-           hd[w * 8 + 1] / n, hd[w * 8 + 2] / n, hd[w * 8 + 3] / n, n);
-  }
+  auto stamps = [&](const char* what) {
+    uint64_t hd[16];
+    (void)hipMemcpy(hd, dbg, sizeof(hd), hipMemcpyDeviceToHost);
+    printf("%s: workgroup 300, mean s_memtime ticks per slab\n", what);
+    for (int w = 0; w < 2; ++w) {
+      const double n = hd[w * 8 + 4] ? (double)hd[w * 8 + 4] : 1.0;
+      printf("  wave %d: wait vmcnt %.0f | barrier %.0f | DMA issue behind the barrier %.0f | ds_read + MFMA (+ late DMA) issue %.0f\n", w * 4, hd[w * 8] / n,
+             hd[w * 8 + 1] / n, hd[w * 8 + 2] / n, hd[w * 8 + 3] / n);
+    }
+  };
+  (void)run<129>(A, W, C2, M, N, K, 2, dbg);
+  stamps("all behind the barrier");
+  (void)run<128>(A, W, C2, M, N, K, 2, dbg);
+  stamps("waves 4..7 at k-step 1 (the product's arrangement)");
+
   std::vector<float> c1(1 << 20), c2(1 << 20);
   (void)hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost);
   (void)hipMemcpy(c2.data(), C2, c2.size() * 4, hipMemcpyDeviceToHost);
