@@ -31,6 +31,169 @@ float run(const __bf16* A, const __bf16* W, float* C, uint32_t M, uint32_t N, ui
   return ms / reps;
 }
 
+// ---- experiment: 32-deep slabs in four LDS buffers, every wave weaves its 4 DMA pieces of slab kt + 3
+// between its MFMAs of slab kt (two slabs of lead: no piece has to land within the slab it is issued in),
+// one barrier per 32-deep slab with a counted vmcnt.  Same MFMA sequence per accumulator as the product
+// kernel: bit-identical results.
+template <int ACT, int PREFETCH>
+__global__ __launch_bounds__(512) void gemm_tn_bf16_ring(const __bf16* __restrict__ A, const __bf16* __restrict__ W,
+                                                         const float* __restrict__ bias, const float* __restrict__ R,
+                                                         float* __restrict__ C, uint32_t M, uint32_t N, uint32_t K,
+                                                         uint32_t ntn, uint64_t ldc) {
+  constexpr uint32_t TM = 256, TN = 256, NW = 8, SBK = 32, MF = 4, NF = 2, WN = 4;
+  constexpr uint32_t ABYTES = TM * SBK * 2, BUF = (TM + TN) * SBK * 2;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // [4][A slab | W slab], rows of 64 bytes
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t nwg = gridDim.x, orig = blockIdx.x;
+  const uint32_t q8 = nwg / 8, r8 = nwg % 8, xcd = orig % 8;
+  const uint32_t wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + orig / 8;
+  const uint32_t ntm = nwg / ntn;
+  constexpr uint32_t GM = 8;
+  const uint32_t group = wgid / (GM * ntn), in_group = wgid % (GM * ntn);
+  const uint32_t gm = ntm - group * GM < GM ? ntm - group * GM : GM;
+  const uint64_t m0 = (uint64_t)(group * GM + in_group % gm) * TM, n0 = (uint64_t)(in_group / gm) * TN;
+  const uint32_t wm = (wave / WN) * (32 * MF), wn = (wave % WN) * (32 * NF);
+  floatx16 acc[MF][NF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  // piece q of an operand image = rows 16 q .. 16 q + 15 (1 KiB); LDS chunk c of row r holds the
+  // row's 16-byte chunk c ^ ((r >> 2) & 3).  Wave w moves A pieces w, w + 8 and W pieces w, w + 8.
+  const __bf16* src[4];
+  uint32_t dst[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const uint32_t q = wave + 8u * (p & 1), chunk = q * 64u + lane, row = chunk >> 2, c = (chunk & 3u) ^ ((row >> 2) & 3u);
+    if (p < 2) {
+      const uint64_t ra = m0 + row < M ? m0 + row : (uint64_t)M - 1;
+      src[p] = A + ra * K + c * 8u;
+      dst[p] = q * 1024u;
+    } else {
+      const uint64_t rw = n0 + row < N ? n0 + row : (uint64_t)N - 1;
+      src[p] = W + rw * K + c * 8u;
+      dst[p] = ABYTES + q * 1024u;
+    }
+  }
+  auto piece = [&](int p, uint32_t kt) {
+    __builtin_amdgcn_global_load_lds((isl_glb_void*)(src[p] + (uint64_t)kt * SBK), (isl_lds_void*)(lds + (kt & 3u) * BUF + dst[p]), 16, 0, 0);
+  };
+  const uint32_t kh = lane >> 5, c32 = lane & 31;
+  const uint32_t nk = K / SBK;
+#pragma unroll
+  for (int s0 = 0; s0 < 3; ++s0)
+    if ((uint32_t)s0 < nk) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) piece(p, s0);
+    }
+  auto frags_b = [&](const unsigned char* wb, uint32_t ks, bf16x8 (&b)[NF]) {
+    const uint32_t cl = 2 * ks + kh;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+      const uint32_t rb = wn + 32 * j + c32;
+      b[j] = *reinterpret_cast<const bf16x8*>(wb + rb * 64u + ((cl ^ ((rb >> 2) & 3u)) << 4));
+    }
+  };
+  auto frag_a = [&](const unsigned char* ab, uint32_t ks, int i) {
+    const uint32_t cl = 2 * ks + kh, ra = wm + 32 * i + c32;
+    return *reinterpret_cast<const bf16x8*>(ab + ra * 64u + ((cl ^ ((ra >> 2) & 3u)) << 4));
+  };
+  bf16x8 pb[NF], pa[MF];  // PREFETCH: the fragments of k-step 0 of the next slab, read before its barrier
+  if (PREFETCH) {
+    if (nk >= 3) __builtin_amdgcn_s_waitcnt(0x0F78);  // slab 0 has landed: at most slabs 1 and 2 outstanding
+    else if (nk == 2) __builtin_amdgcn_s_waitcnt(0x0F74);
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    frags_b(lds + ABYTES, 0, pb);
+#pragma unroll
+    for (int i = 0; i < MF; ++i) pa[i] = frag_a(lds, 0, i);
+  }
+  for (uint32_t kt = 0; kt < nk; ++kt) {
+    if (!PREFETCH) {
+      // slab kt has landed when at most the pieces of the later slabs are outstanding
+      const uint32_t later = (kt + 2 < nk ? kt + 2 : nk - 1) - kt;  // slabs issued beyond kt: 0, 1 or 2
+      if (later >= 2) __builtin_amdgcn_s_waitcnt(0x0F78);
+      else if (later == 1) __builtin_amdgcn_s_waitcnt(0x0F74);
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+    }
+    const bool more = kt + 3 < nk;
+    const unsigned char* ab = lds + (kt & 3u) * BUF;
+    const unsigned char* wb = ab + ABYTES;
+#pragma unroll
+    for (uint32_t ks = 0; ks < 2; ++ks) {
+      bf16x8 b[NF];
+      if (PREFETCH && ks == 0) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j) b[j] = pb[j];
+      } else {
+        frags_b(wb, ks, b);
+      }
+      if (PREFETCH && ks == 1 && kt + 1 < nk) {
+        // slab kt + 1 must have landed for everyone before its first fragments are read: the barrier
+        // of slab kt + 1, taken one k-step early
+        // (outstanding then: the pieces of slab kt + 2, issued behind the previous such barrier; those of
+        // slab kt + 3 go out behind this one, into the buffer slab kt - 1 has just left)
+        if (kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0F74);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+      }
+#pragma unroll
+      for (int i = 0; i < MF; ++i) {
+        const bf16x8 a = (PREFETCH && ks == 0) ? pa[i] : frag_a(ab, ks, i);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[i][j], 0, 0, 0);
+        if (PREFETCH) {
+          if (ks == 1 && more) piece(i, kt + 3);
+        } else if ((i & 1) == 1 && more) {
+          piece((int)ks * 2 + i / 2, kt + 3);
+        }
+      }
+      if (PREFETCH && ks == 1 && kt + 1 < nk) {
+        const unsigned char* nab = lds + ((kt + 1) & 3u) * BUF;
+        frags_b(nab + ABYTES, 0, pb);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) pa[i] = frag_a(nab, 0, i);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+      const uint64_t n = n0 + wn + j * 32 + c32;
+      if (n >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint64_t m = m0 + wm + i * 32 + 8 * (r / 4) + 4 * kh + (r % 4);
+        if (m >= M) continue;
+        C[m * ldc + n] = -acc[i][j][r];  // EPI_DOT
+      }
+    }
+}
+
+template <int PREFETCH>
+float run_ring(const __bf16* A, const __bf16* W, float* C, uint32_t M, uint32_t N, uint32_t K, int reps) {
+  auto kern = gemm_tn_bf16_ring<EPI_DOT, PREFETCH>;
+  constexpr size_t lds = 4 * (256 + 256) * 32 * 2;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const uint32_t ntn = (N + 255) / 256, ntiles = ((M + 255) / 256) * ntn;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL(kern, dim3(ntiles), dim3(512), lds, 0, A, W, nullptr, nullptr, C, M, N, K, ntn, (uint64_t)N);
+  (void)hipEventRecord(e0);
+  for (int r = 0; r < reps; ++r)
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(512), lds, 0, A, W, nullptr, nullptr, C, M, N, K, ntn, (uint64_t)N);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms / reps;
+}
+
 int main(int argc, char** argv) {
   const uint32_t M = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 2 ? atoi(argv[2]) : 65536, K = argc > 3 ? atoi(argv[3]) : 4096;
   __bf16 *A, *W;
@@ -75,6 +238,27 @@ int main(int argc, char** argv) {
 
     printf("M=%u N=%u K=%u  all behind the barrier %.3f ms %.1f TF | waves 4..7 at k-step 2 %.3f ms %.1f TF | at 1 %.3f ms %.1f TF | at 3 %.3f ms %.1f TF\n", M, N, K,
            t0, fl / t0 / 1e9, t1, fl / t1 / 1e9, t2, fl / t2 / 1e9, t3, fl / t3 / 1e9);
+  }
+  {
+    float* C3;
+    (void)hipMalloc(&C3, (size_t)M * N * 4);
+    for (int round = 0; round < 3; ++round) {
+      const float tr0 = run_ring<0>(A, W, C3, M, N, K, 40);
+      const float tr1 = run_ring<1>(A, W, C3, M, N, K, 40);
+      printf("ring (4 x 32-deep buffers, pieces woven): %.3f ms %.1f TF | + first fragments read before the barrier: %.3f ms %.1f TF\n", tr0,
+             fl / tr0 / 1e9, tr1, fl / tr1 / 1e9);
+    }
+    (void)run_ring<0>(A, W, C3, M, N, K, 1);
+    std::vector<float> c1(1 << 20), c3(1 << 20);
+    (void)hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(c3.data(), C3, c3.size() * 4, hipMemcpyDeviceToHost);
+    size_t diff = 0;
+    for (size_t i = 0; i < c1.size(); ++i) diff += c1[i] != c3[i];
+    (void)run_ring<1>(A, W, C3, M, N, K, 1);
+    (void)hipMemcpy(c3.data(), C3, c3.size() * 4, hipMemcpyDeviceToHost);
+    size_t diff1 = 0;
+    for (size_t i = 0; i < c1.size(); ++i) diff1 += c1[i] != c3[i];
+    printf("ring vs product kernel, differing elements among the first 2^20: %zu / %zu (prefetch variant)\n", diff, diff1);
   }
   auto stamps = [&](const char* what) {
     uint64_t hd[16];
