@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
+#include <algorithm>
 #include <vector>
 #include "gemm_bf16.hip.h"
 using namespace isl_gemm;
@@ -230,11 +232,19 @@ int main(int argc, char** argv) {
   }
   g_rn = rn;
   g_qn = qn;
+
+  float* C3m;
+  (void)hipMalloc(&C3m, (size_t)M * N * 4);
   for (int round = 0; round < 3; ++round) {
-    const float t0 = run<1>(A, W, C, M, N, K, 40, dbg);
-    const float t1 = run<8>(A, W, C2, M, N, K, 40, dbg);
-    const float t2 = run<0>(A, W, C2, M, N, K, 40, dbg);
-    const float t3 = run<12>(A, W, C2, M, N, K, 40, dbg);
+    const float t0 = run<65>(A, W, C, M, N, K, 40, dbg);
+    const float t1 = run<72>(A, W, C2, M, N, K, 40, dbg);
+    const float t2 = run<64>(A, W, C2, M, N, K, 40, dbg);
+    const float t3 = run<76>(A, W, C2, M, N, K, 40, dbg);
+    const float tm = run<0>(A, W, C3m, M, N, K, 40, dbg);
+    const float tcos = run<0, EPI_COSINE>(A, W, C2, M, N, K, 40, dbg);
+    const float tcos32 = run<64, EPI_COSINE>(A, W, C2, M, N, K, 40, dbg);
+    printf("cosine epilogue: product kernel %.3f ms %.1f TF | 32x32x16 %.3f ms %.1f TF\n", tcos, fl / tcos / 1e9, tcos32, fl / tcos32 / 1e9);
+    printf("16x16x32 MFMAs (the product kernel; the variants below use 32x32x16): %.3f ms %.1f TF\n", tm, fl / tm / 1e9);
 
     printf("M=%u N=%u K=%u  all behind the barrier %.3f ms %.1f TF | waves 4..7 at k-step 2 %.3f ms %.1f TF | at 1 %.3f ms %.1f TF | at 3 %.3f ms %.1f TF\n", M, N, K,
            t0, fl / t0 / 1e9, t1, fl / t1 / 1e9, t2, fl / t2 / 1e9, t3, fl / t3 / 1e9);
@@ -260,6 +270,14 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < c1.size(); ++i) diff1 += c1[i] != c3[i];
     printf("ring vs product kernel, differing elements among the first 2^20: %zu / %zu (prefetch variant)\n", diff, diff1);
   }
+  {
+    std::vector<float> c1(1 << 20), c3(1 << 20);
+    (void)hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(c3.data(), C3m, c3.size() * 4, hipMemcpyDeviceToHost);
+    double md = 0, mx = 0;
+    for (size_t i = 0; i < c1.size(); ++i) { md = std::max(md, (double)fabsf(c1[i] - c3[i])); mx = std::max(mx, (double)fabsf(c1[i])); }
+    printf("16x16x32 vs 32x32x16: max |difference| %.3g on values up to %.3g\n", md, mx);
+  }
   auto stamps = [&](const char* what) {
     uint64_t hd[16];
     (void)hipMemcpy(hd, dbg, sizeof(hd), hipMemcpyDeviceToHost);
@@ -270,10 +288,12 @@ int main(int argc, char** argv) {
              hd[w * 8 + 1] / n, hd[w * 8 + 2] / n, hd[w * 8 + 3] / n);
     }
   };
-  (void)run<129>(A, W, C2, M, N, K, 2, dbg);
+  (void)run<193>(A, W, C2, M, N, K, 2, dbg);
   stamps("all behind the barrier");
+  (void)run<192>(A, W, C2, M, N, K, 2, dbg);
+  stamps("waves 4..7 at k-step 1, 32x32x16");
   (void)run<128>(A, W, C2, M, N, K, 2, dbg);
-  stamps("waves 4..7 at k-step 1 (the product's arrangement)");
+  stamps("the product kernel (16x16x32, waves 4..7 behind the first MFMA groups)");
 
   std::vector<float> c1(1 << 20), c2(1 << 20);
   (void)hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost);
