@@ -286,7 +286,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_bf16_dma(const __bf16* _
         for (int i = 0; i < 2 * MF; ++i) {
 #pragma unroll
           for (int j = 0; j < 2 * NF; ++j) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc4[i][j], 0, 0, 0);
-          if (s32 == 0 && i == MF - 1 && late && kt + 1 < nk) issue((kt + 1) * HBK, (kt + 1) & 1);
+          // (EXP bits 2-3 move the late waves' issue point: after MFMA group 1 / 2 / 6 of 16 instead of 4)
+          constexpr int LATE_AT = ((EXP >> 2) & 3) == 1 ? 0 : ((EXP >> 2) & 3) == 2 ? 1 : ((EXP >> 2) & 3) == 3 ? 5 : MF - 1;
+          if (s32 == 0 && i == LATE_AT && late && kt + 1 < nk) issue((kt + 1) * HBK, (kt + 1) & 1);
         }
       }
     } else {

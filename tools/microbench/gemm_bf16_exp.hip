@@ -241,6 +241,9 @@ int main(int argc, char** argv) {
     const float t2 = run<64>(A, W, C2, M, N, K, 40, dbg);
     const float t3 = run<76>(A, W, C2, M, N, K, 40, dbg);
     const float tm = run<0>(A, W, C3m, M, N, K, 40, dbg);
+    const float tl1 = run<4>(A, W, C2, M, N, K, 40, dbg), tl2 = run<8>(A, W, C2, M, N, K, 40, dbg), tl3 = run<12>(A, W, C2, M, N, K, 40, dbg), tl0 = run<1>(A, W, C2, M, N, K, 40, dbg);
+    printf("16x16x32, late waves issue after MFMA group 1 / 2 / 4 (product) / 6 of 16, or with the others: %.1f / %.1f / %.1f / %.1f / %.1f TF\n", fl / tl1 / 1e9, fl / tl2 / 1e9,
+           fl / tm / 1e9, fl / tl3 / 1e9, fl / tl0 / 1e9);
     const float tcos = run<0, EPI_COSINE>(A, W, C2, M, N, K, 40, dbg);
     const float tcos32 = run<64, EPI_COSINE>(A, W, C2, M, N, K, 40, dbg);
     printf("cosine epilogue: product kernel %.3f ms %.1f TF | 32x32x16 %.3f ms %.1f TF\n", tcos, fl / tcos / 1e9, tcos32, fl / tcos32 / 1e9);
