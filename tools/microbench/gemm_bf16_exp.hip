@@ -176,6 +176,26 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_ring(const __bf16* __restric
     }
 }
 
+// four waves per 256 x 256 tile, 128 x 128 per wave (hipBLASLt's decomposition), compiler-scheduled
+float run_w4(const __bf16* A, const __bf16* W, float* C, uint32_t M, uint32_t N, uint32_t K, int reps) {
+  auto kern = gemm_tn_bf16_dma<EPI_DOT, false, false, 2, 2, 4, 4, 0>;
+  constexpr size_t lds = 2 * (256 + 256) * HBK * 2;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const uint32_t ntn = (N + 255) / 256, ntiles = ((M + 255) / 256) * ntn;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), lds, 0, A, W, nullptr, nullptr, C, M, N, K, ntn, (uint64_t)N, (uint64_t*)nullptr);
+  (void)hipEventRecord(e0);
+  for (int r = 0; r < reps; ++r)
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), lds, 0, A, W, nullptr, nullptr, C, M, N, K, ntn, (uint64_t)N, (uint64_t*)nullptr);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms / reps;
+}
+
 template <int PREFETCH>
 float run_ring(const __bf16* A, const __bf16* W, float* C, uint32_t M, uint32_t N, uint32_t K, int reps) {
   auto kern = gemm_tn_bf16_ring<EPI_DOT, PREFETCH>;
@@ -256,6 +276,8 @@ int main(int argc, char** argv) {
     float* C3;
     (void)hipMalloc(&C3, (size_t)M * N * 4);
     for (int round = 0; round < 3; ++round) {
+      const float tw4 = run_w4(A, W, C3, M, N, K, 40);
+      printf("four waves per tile, 128 x 128 per wave, 16x16x32: %.3f ms %.1f TF\n", tw4, fl / tw4 / 1e9);
       const float tr0 = run_ring<0>(A, W, C3, M, N, K, 40);
       const float tr1 = run_ring<1>(A, W, C3, M, N, K, 40);
       printf("ring (4 x 32-deep buffers, pieces woven): %.3f ms %.1f TF | + first fragments read before the barrier: %.3f ms %.1f TF\n", tr0,
