@@ -413,12 +413,14 @@ def test_pq_matches_oracle(orc):  # pq.rs:639-677, 787-809, 505-520
 
 
 # ------------------------------------------------ distance matrix on the matrix cores
-@pytest.mark.parametrize("nq,n,d", [(300, 1030, 32), (513, 1024, 96), (700, 131074, 64), (600, 100001, 96)])
+@pytest.mark.parametrize("nq,n,d", [(300, 1030, 32), (513, 1024, 96), (700, 131074, 64), (600, 100001, 96),
+                                    (2048, 4100, 64), (2048, 4100, 96)])
 def test_distance_matrix_tile_walk(orc, nq, n, d):
     """The LDS-DMA float32 GEMM (d % 32 == 0): one slab and several, row counts that are and are not
     multiples of 4 (vector and per-element epilogue), ragged last tiles, and -- the two large cases --
     the persistent 256 x 256 variant whose workgroups walk several tiles with an even and an odd
-    number of slabs (the buffer parity carried from tile to tile).  Whole matrix against a float64
+    number of slabs (the buffer parity carried from tile to tile); the last two walk tiles in the
+    128 x 128 variant (528 tiles on 512 resident workgroups).  Whole matrix against a float64
     product, sampled query rows against the reference's batch_calculate."""
     rows = clustered_vectors(n, d, 13)
     q = clustered_vectors(nq, d, 14)
