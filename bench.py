@@ -182,7 +182,7 @@ def main():
     ap.add_argument("--no-replica", action="store_true",
                     help="multi-GPU shard runs: skip the extra replica-mode measurement")
     ap.add_argument("--distinct-batches", type=int, default=4)
-    ap.add_argument("--pipeline", type=int, default=8,
+    ap.add_argument("--pipeline", type=int, default=16,
                     help="searches kept in flight (isl_search_batch_device_async); 1 = synchronous")
     args = ap.parse_args()
 
