@@ -182,8 +182,9 @@ def main():
     ap.add_argument("--no-replica", action="store_true",
                     help="multi-GPU shard runs: skip the extra replica-mode measurement")
     ap.add_argument("--distinct-batches", type=int, default=4)
-    ap.add_argument("--pipeline", type=int, default=16,
-                    help="searches kept in flight (isl_search_batch_device_async); 1 = synchronous")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="searches kept in flight (isl_search_batch_device_async); 1 = synchronous; default 16 on "
+                         "one GPU, 12 per rank in multi-GPU runs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -258,7 +259,10 @@ def main():
         # every lane's buffers, the padded adjacency and the exact-kernel pool up front: nothing on
         # the search path allocates or synchronises for set-up afterwards (isl_index_prepare), so
         # the timed region does not depend on --warmup
-        depth = max(1, min(args.pipeline, 16))
+        # One stream per search in flight: 16 (all lanes) is the best measured on one GPU; past ~20 streams
+        # on a card the runtime's 32 hardware queues run out and the rate collapses (24 lanes: 0.39 M q/s),
+        # so ranks that also run the exchange's side stream and RCCL's own keep a margin.
+        depth = max(1, min(args.pipeline if args.pipeline > 0 else (16 if world == 1 else 12), 16))
         idx.prepare(nq, ef, k, depth)
         torch.cuda.synchronize()
         log(f"index resident and {depth} search lanes prepared in {time.time() - t0:.1f}s")
