@@ -7,12 +7,14 @@ One "step" = one pass of the hot path (isl_search_batch_device) over one batch o
 that is already resident in HBM.
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N ...            (no launcher: starts N ranks itself, before any GPU call)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Multi-GPU (N > 1), mode "shard" (default, the north star's layout): the index is sharded by
 node-id range, every rank searches the whole query batch in its own sub-graph, the
-per-shard top-k are exchanged with one RCCL all-gather and merged by isl_merge_topk
-(MultiIndexSearcher::search semantics, src/core/search.rs:211-237).  Total index size and
+per-shard top-k are exchanged with one RCCL all-gather and merged, all inside the library
+(isl_sharded_submit / isl_sharded_result: MultiIndexSearcher::search semantics,
+src/core/search.rs:211-237).  Total index size and
 query count are fixed as N grows -> "strong" scaling.  Mode "replica": every rank holds the
 full index and answers its own batch, no data-path collective -> "weak".
 
@@ -51,9 +53,12 @@ def algorithmic_bytes(st: dict, d: int, k: int, elem: int = 4) -> float:
             st["queries"] * (4 * d + 12 * k))
 
 
-def cpu_baseline(x, offsets, neighbours, entry, queries, k, ef, budget_s=25.0):
-    """Times the CPU oracle (the restated reference algorithm) on this box's host cores.
-    The oracle is only the checker / baseline here, never the measured product."""
+def cpu_baseline(x, offsets, neighbours, entry, qsets, k, ef, leg_s=10.0):
+    """Times the CPU oracle (the restated reference algorithm) on this box's host cores: one thread
+    (the reference is single-threaded per query and per batch, search.rs:179-181) and all cores, each
+    leg for `leg_s` seconds of wall time over the run's query batches in turn (a leg of a second would
+    be dominated by thread start-up).  The oracle is only the checker / baseline here, never the
+    measured product."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
 
@@ -63,44 +68,49 @@ def cpu_baseline(x, offsets, neighbours, entry, queries, k, ef, budget_s=25.0):
     off = offsets.cpu().numpy().astype(np.uint64)
     nb = neighbours.cpu().numpy().astype(np.uint64)
     csr = orc.Csr(off, nb, entry_point=entry)
-    q = queries.cpu().numpy()
+    q = np.concatenate([qb.cpu().numpy() for qb in qsets], 0)
     log(f"cpu_baseline: host copy of the index took {time.time() - t0:.1f}s")
-    # calibrate on a few queries, then size the sample to the time budget
-    t0 = time.time()
-    for i in range(4):
+    for i in range(4):  # page the index in
         orc.leann_search(csr, xv, q[i], k, ef, copy_per_node=True)
-    per_q = (time.time() - t0) / 4
     ncores = os.cpu_count() or 1
     try:
         ncores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
     threads = max(1, min(ncores, 64))
-    n1 = int(max(8, min(q.shape[0], (budget_s / 2) / max(per_q, 1e-6))))
-    t0 = time.time()
-    for i in range(n1):
-        orc.leann_search(csr, xv, q[i], k, ef, copy_per_node=True)
-    qps_1 = n1 / (time.time() - t0)
-    nm = int(max(threads, min(q.shape[0], (budget_s / 2) * qps_1 * threads * 0.7)))
 
-    def work(lo, hi):
-        for i in range(lo, hi):
-            orc.leann_search(csr, xv, q[i % q.shape[0]], k, ef, copy_per_node=True)
+    def leg(nthreads, seconds):
+        done = [0] * nthreads
+        start = threading.Barrier(nthreads + 1)
 
-    bounds = np.linspace(0, nm, threads + 1).astype(int)
-    ths = [threading.Thread(target=work, args=(bounds[t], bounds[t + 1])) for t in range(threads)]
-    t0 = time.time()
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    qps_m = nm / (time.time() - t0)
+        def work(t):
+            start.wait()
+            end = time.perf_counter() + seconds
+            i, n = t, 0
+            while time.perf_counter() < end:  # thread t answers queries t, t + T, t + 2T, ... of the batches
+                orc.leann_search(csr, xv, q[i % q.shape[0]], k, ef, copy_per_node=True)
+                i += nthreads
+                n += 1
+            done[t] = n
+
+        ths = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+        for t in ths:
+            t.start()
+        start.wait()  # the clock starts once every thread exists
+        t0 = time.perf_counter()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+        return sum(done), dt
+
+    n1, dt1 = leg(1, leg_s)
+    nm, dtm = leg(threads, leg_s)
     return {
-        "value": round(qps_m, 2), "unit": "queries/s", "cores": threads, "kind": "port",
-        "value_1thread": round(qps_1, 2),
-        "sample": f"{nm} queries of the same batch on {threads} threads (queries statically "
-                  f"partitioned; ctypes releases the GIL), {n1} queries on 1 thread; "
-                  "copy-per-node provider as in leann.rs:145-154; same graph, ef and k",
+        "value": round(nm / dtm, 2), "unit": "queries/s", "cores": threads, "kind": "port",
+        "value_1thread": round(n1 / dt1, 2),
+        "sample": f"{nm} queries in {dtm:.1f} s on {threads} threads (thread t takes every {threads}th query of "
+                  f"the run's {len(qsets)} batches; ctypes releases the GIL), {n1} queries in {dt1:.1f} s on 1 "
+                  "thread; copy-per-node provider as in leann.rs:145-154; same graph, ef and k",
     }
 
 
@@ -155,6 +165,56 @@ def measure_traffic(args):
             "traffic_over_algorithmic": round(traffic / alg, 4) if alg else None}
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- as children of
+    torch.distributed.run, one per GPU -- BEFORE this process has made any GPU call (it never does),
+    and pass their exit code and rank 0's JSON line through.  Never a re-exec: a process that has
+    initialised the GPU must not be replaced."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {n} without WORLD_SIZE: launching {n} ranks on 127.0.0.1:{port}")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, world, rank, backend):
+    """The launch plumbing without a card: rendezvous, ONE all-gather of a packed record of the
+    run's (nq, k) over the process group, the count of ranks that got through it, the JSON line."""
+    from islands_amd.sharded import record_bytes, record_views, shard_range
+
+    nq, k = args.nq, args.k
+    B = record_bytes(nq, k)
+    rec = torch.zeros(B, dtype=torch.uint8)
+    ids, dd, cnt = record_views(rec, nq, k)
+    ids.fill_(rank); dd.fill_(float(rank)); cnt.fill_(k)
+    gathered = torch.zeros((world, B), dtype=torch.uint8)
+    if world > 1:
+        dist.all_gather_into_tensor(gathered.view(-1), rec)
+    else:
+        gathered[0].copy_(rec)
+    g_ids, g_dd, g_cnt = record_views(gathered, nq, k)
+    ok = all(bool((g_ids[r] == r).all()) and bool((g_cnt[r] == k).all()) for r in range(world))
+    done = torch.tensor([1 if ok else 0], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(done)
+    if rank == 0:
+        print(json.dumps({"metric": "queries/sec @ recall@10>=0.95, 10Mx768 ef=128", "value": None,
+                          "unit": "queries/s", "n_gpus": int(done.item()), "steps": args.steps, "warmup": args.warmup,
+                          "dry_run": True, "backend": backend,
+                          "config": {"workload": "dry run: no search", "shard_ranges": [
+                              list(shard_range(args.nodes, r, world)) for r in range(world)]}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,11 +241,20 @@ def main():
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-replica", action="store_true",
                     help="multi-GPU shard runs: skip the extra replica-mode measurement")
-    ap.add_argument("--distinct-batches", type=int, default=4)
+    ap.add_argument("--distinct-batches", type=int, default=0,
+                    help="query batches the steps cycle through, each with its own ground truth; default (0) = "
+                         "steps + warmup, so that no two launches in flight (or anywhere in the run) traverse "
+                         "the same queries (round 2 cycled 4 batches under 16 launches in flight)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous, one all-gather of a packed record over the process group and the JSON "
+                         "line only (no GPU work): the launch plumbing of --gpus N, testable without a card")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="searches kept in flight (isl_search_batch_device_async); 1 = synchronous; default 16 on "
                          "one GPU, 12 per rank in multi-GPU runs")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))  # this process stays off the GPU
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -193,7 +262,14 @@ def main():
     # ISL_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks
     # share a card, the exchange goes through host memory); the real runs use RCCL ("nccl").
     backend = os.environ.get("ISL_BENCH_BACKEND", "nccl")
+    if args.dry_run:
+        if world > 1:
+            dist.init_process_group("gloo")
+        return dry_run(args, world, rank, "gloo")
     ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"bench.py: {world} ranks but {ndev} GPU(s) visible (RCCL needs one card per rank; "
+                         "ISL_BENCH_BACKEND=gloo is the rehearsal mode for ranks that share a card)")
     dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -219,6 +295,8 @@ def main():
     import synth  # the synthetic-workload harness (data, bench graph, ground truth): not product code
 
     N, d, nq, k, ef = args.nodes, args.dim, args.nq, args.k, args.ef
+    comm_info = {}
+
     def measure(mode):
         """One full measurement (setup, warm-up, timed steps) in `mode`; returns the result
         object and what the CPU baseline needs."""
@@ -233,8 +311,7 @@ def main():
         # ---------------- setup (untimed): data, graph, index upload, queries, ground truth
         t0 = time.time()
         if args.dataset == "U":
-            x = synth.make_uniform(N, d, 42, device=dev)[lo:hi].contiguous() if shard_mode else \
-                synth.make_uniform(N, d, 42, device=dev)
+            x = synth.make_uniform(n_local, d, 42, device=dev, start=lo)  # this rank's rows only
         else:
             x = synth.make_rows(N, d, lo, n_local, per_cluster=args.per_cluster, device=dev)
         x16 = None
@@ -267,7 +344,8 @@ def main():
         torch.cuda.synchronize()
         log(f"index resident and {depth} search lanes prepared in {time.time() - t0:.1f}s")
 
-        nb_batches = max(1, min(args.distinct_batches, args.steps + args.warmup))
+        nb_batches = args.steps + args.warmup if args.distinct_batches <= 0 else \
+            max(1, min(args.distinct_batches, args.steps + args.warmup))
         qsets, truths = [], []
         for b in range(nb_batches):
             # replica mode: every rank answers its own batches; shard mode: same batch on all ranks
@@ -292,7 +370,11 @@ def main():
             # host wait (islands_amd/sharded.py); the exchange of a batch overlaps the traversals of
             # the batches submitted after it
             from islands_amd.sharded import ShardedSearcher
-            searcher = ShardedSearcher(N, index=idx, device=dev, depth=depth).prepare(nq, k, ef)
+            # RCCL communicator of the library's own (unique id carried over the torch process group);
+            # the gloo rehearsal (ranks sharing a card) exchanges through host memory instead
+            searcher = ShardedSearcher(N, index=idx, device=dev, depth=depth,
+                                       transport="rccl" if backend == "nccl" else "host").prepare(nq, k, ef)
+            comm_info.update(searcher.shard_group.info())
             # exact global truth = merge of the per-shard exact top-k (same collective + merge)
             g_truth = []
             for (ti, td) in truths:
@@ -368,10 +450,17 @@ def main():
                 " ".join(f"{b}:{(t - t0) * 1e3:.2f}/{km:.2f}" for b, t, km in trace) + f"  end {elapsed * 1e3:.2f}")
         if shard_mode:
             searcher.check_flags()
+        ranks_done = 1
         if world > 1:
             tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
+            # ranks that came through every exchange of the timed region
+            one = torch.ones(1, device=dev if backend == "nccl" else "cpu", dtype=torch.int64)
+            dist.all_reduce(one)
+            ranks_done = int(one.item())
+            if shard_mode and comm_info.get("comm_ranks") not in (None, ranks_done):
+                raise RuntimeError(f"communicator has {comm_info.get('comm_ranks')} ranks, {ranks_done} completed")
 
         ref_ids = {b: ids_b for (b, ids_b, cnt_b) in recalls} if not shard_mode else {}
         rec = []
@@ -379,6 +468,8 @@ def main():
             truth = g_truth[b] if shard_mode else truths[b][0]
             rec.append(synth.recall_at_k(ids_b, cnt_b, truth))
         recall = float(np.mean(rec)) if rec else 0.0
+        if shard_mode:
+            searcher.close()  # communicator, side stream and slots go before the next measurement
 
         queries_per_step = nq if (world == 1 or shard_mode) else nq * world
         value = queries_per_step * args.steps / elapsed
@@ -396,7 +487,7 @@ def main():
             "metric": "queries/sec @ recall@10>=0.95, 10Mx768 ef=128",
             "value": round(value, 2),
             "unit": "queries/s",
-            "n_gpus": world,
+            "n_gpus": ranks_done,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -417,6 +508,8 @@ def main():
                                 (f"shard{world}: node-id ranges, RCCL all-gather + top-k merge"
                                  if shard_mode else f"replica{world}")),
                 "searches_in_flight": depth,
+                "distinct_batches": nb_batches,
+                "exchange": (dict(comm_info, ranks_completed=ranks_done) if shard_mode else None),
                 "per_query": {"expansions": round(agg["expansions"] / max(agg["queries"], 1), 1),
                               "edges": round(agg["edges"] / max(agg["queries"], 1), 1),
                               "evals": round(agg["evals"] / max(agg["queries"], 1), 1)},
@@ -503,7 +596,7 @@ def main():
             result["roofline"]["traffic_source"] = f"not measured: {e!r}"[:300]
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.traffic_child:
         try:
-            result["cpu_baseline"] = cpu_baseline(x, offsets, neighbours, entry, qsets[0], k, ef)
+            result["cpu_baseline"] = cpu_baseline(x, offsets, neighbours, entry, qsets, k, ef)
         except Exception as e:  # the baseline must never take the measured number down with it
             result["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0,
                                       "kind": "port", "sample": f"failed: {e!r}"}

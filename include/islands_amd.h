@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISL_ABI_VERSION 2
+#define ISL_ABI_VERSION 3
 
 typedef int32_t isl_status;
 
@@ -323,6 +323,74 @@ isl_status isl_merge_topk_packed_async(uint64_t nlists, uint64_t nq, uint64_t k,
                                        uint64_t list_stride, const uint64_t* d_id_base, uint64_t top_k,
                                        uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_src,
                                        uint32_t* d_out_count, uint32_t* d_flags, int32_t device, void* stream);
+/* ---- multi-GPU: the index sharded by node-id range, one process (rank) per GPU ----
+ * Semantics = MultiIndexSearcher::search (src/core/search.rs:211-237) and the product's cross-index
+ * merge (src/indexer/service.rs:775-801) with one sub-index per rank: every rank answers the whole
+ * query batch in its own sub-graph (local ids), the per-rank top-k lists are concatenated in rank
+ * order, stable-sorted by distance (ties -> the lower rank) and truncated to k; global id = the
+ * rank's id base + local id.  The exchange is ONE collective per batch -- an all-gather of every
+ * rank's packed answer record (isl_shard_record_bytes) -- issued on a side stream behind a device
+ * event of the search, followed by the merge kernel on that stream: the host only submits, and the
+ * exchange of batch i overlaps the traversals of batches i+1.. on the index's lanes.
+ *
+ * isl_shard_group = the communicator of the R ranks.  Two transports:
+ *   - RCCL (xGMI): rank 0 calls isl_shard_unique_id, hands the 128 bytes to every rank by whatever
+ *     means the host has (the reference product would use its own RPC; the tests use a store), and
+ *     every rank calls isl_shard_group_create -- ncclCommInitRank, collective over the ranks.
+ *     librccl.so is loaded on first use (the copy already in the process, if any).
+ *   - host: `allgather(user, send, recv, bytes)` is a blocking all-gather of `bytes` from every rank
+ *     into recv (rank-major) over host memory, supplied by the caller (MPI, gloo, a socket ...): for
+ *     boxes without xGMI between the ranks' cards and for tests where ranks share one card.  The
+ *     exchange is then synchronous inside isl_sharded_submit.
+ * world == 1 needs no group (pass NULL to isl_sharded_searcher_new). */
+#define ISL_SHARD_UNIQUE_ID_BYTES 128
+typedef struct isl_shard_group isl_shard_group;
+typedef int32_t (*isl_shard_allgather_fn)(void* user, const void* send, void* recv, uint64_t bytes);
+isl_status isl_shard_unique_id(uint8_t id[ISL_SHARD_UNIQUE_ID_BYTES]);
+isl_status isl_shard_group_create(int32_t device, int32_t world, int32_t rank,
+                                  const uint8_t id[ISL_SHARD_UNIQUE_ID_BYTES], isl_shard_group** out);
+isl_status isl_shard_group_create_host(int32_t device, int32_t world, int32_t rank,
+                                       isl_shard_allgather_fn allgather, void* user, isl_shard_group** out);
+/* world / rank as created; *comm_ranks = what the communicator itself reports (ncclCommCount; the
+ * host transport reports `world`); *is_rccl = 1 for the RCCL transport. */
+isl_status isl_shard_group_info(const isl_shard_group* grp, int32_t* world, int32_t* rank, int32_t* comm_ranks,
+                                int32_t* is_rccl);
+void isl_shard_group_free(isl_shard_group* grp);
+
+/* The searcher of one rank: `shard` is this rank's LeannIndex over its id range (resident, provider
+ * attached; borrowed, must outlive the searcher).  id_base[r] = first global id of rank r; NULL =
+ * even ranges of n_total, rank r owns [r*n_total/R, (r+1)*n_total/R).  Up to `depth` (1..16)
+ * batches in flight. */
+typedef struct isl_sharded_searcher isl_sharded_searcher;
+isl_status isl_sharded_searcher_new(const isl_index* shard, isl_shard_group* grp, uint64_t n_total,
+                                    const uint64_t* id_base, int32_t depth, isl_sharded_searcher** out);
+void isl_sharded_searcher_free(isl_sharded_searcher* s);
+/* Buffers for `depth` batches of up to max_nq queries / max_k results, and isl_index_prepare on the
+ * shard: nothing allocates on the submit path afterwards.  Collective over the ranks with the RCCL
+ * transport (the communicator's first all-gather, which sets up its channels, is made here). */
+isl_status isl_sharded_prepare(isl_sharded_searcher* s, uint64_t max_nq, uint64_t max_k, uint64_t max_ef);
+/* Enqueues one batch (queries on the device, ordered after the work already on `stream`): shard
+ * search -> all-gather of the records -> merge.  Every rank must submit the same batches in the
+ * same order.  Returns a handle; nothing is waited for (RCCL transport). */
+isl_status isl_sharded_submit(isl_sharded_searcher* s, const float* d_queries, uint64_t nq, uint64_t d,
+                              uint64_t k, uint64_t ef, void* stream, uint64_t* handle);
+/* Completes a submitted batch: per-query failures of this rank's shard surface here (the first
+ * failing query's CoreError); the merged answers are on the device -- global ids u64[nq][k],
+ * distances f32[nq][k], source rank u32[nq][k], counts u32[nq] -- and stay valid until `depth`
+ * further batches have been submitted.  `stats` (may be NULL) = this rank's search counters. */
+isl_status isl_sharded_result(isl_sharded_searcher* s, uint64_t handle, const uint64_t** d_ids,
+                              const float** d_dist, const uint32_t** d_src, const uint32_t** d_count,
+                              isl_search_stats* stats);
+/* MultiIndexSearcher::search over the shards with host buffers in and out (submit + result +
+ * copies); out_src may be NULL.  A NaN score in the merge is ISL_ERR_SEARCH (the reference panics,
+ * search.rs:231). */
+isl_status isl_sharded_search_batch(isl_sharded_searcher* s, const float* queries, uint64_t nq, uint64_t d,
+                                    uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dist,
+                                    uint32_t* out_src, uint32_t* out_count);
+/* Merge flags accumulated so far (bit 0: NaN score met, bit 1: a list was not ascending); synchronises
+ * the exchange stream. */
+isl_status isl_sharded_flags(isl_sharded_searcher* s, uint32_t* flags);
+
 /* Product-level merge, src/indexer/service.rs:775-801 (IndexerService::search_with_embeddings):
  * per list the (id, distance) results of one index (searched with ef = max(top_k, 100), :781);
  * results whose id has no file entry are dropped (`files_len[l]` = stored.files.len(), host

@@ -359,7 +359,8 @@ class LeannIndex:
         _ffi.lib().isl_free_bytes(p)
         return data
 
-    def __del__(self):
+    def close(self) -> None:
+        """isl_index_free now (instead of whenever the object is collected)."""
         h = getattr(self, "_h", None)
         if h:
             try:
@@ -367,6 +368,9 @@ class LeannIndex:
             except Exception:
                 pass
             self._h = None
+
+    def __del__(self):
+        self.close()
 
     # accessors, leann.rs:518-546
     def __len__(self) -> int:

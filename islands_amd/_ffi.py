@@ -105,6 +105,20 @@ SIGNATURES = {
     "isl_shard_record_bytes": (u64, [u64, u64]),
     "isl_merge_topk_packed_async": (i32, [u64, u64, u64, C.c_void_p, u64, C.c_void_p, u64, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, i32, C.c_void_p]),
+    "isl_shard_unique_id": (i32, [C.c_void_p]),
+    "isl_shard_group_create": (i32, [i32, i32, i32, C.c_void_p, P(C.c_void_p)]),
+    "isl_shard_group_create_host": (i32, [i32, i32, i32, C.c_void_p, C.c_void_p, P(C.c_void_p)]),
+    "isl_shard_group_info": (i32, [C.c_void_p, P(i32), P(i32), P(i32), P(i32)]),
+    "isl_shard_group_free": (None, [C.c_void_p]),
+    "isl_sharded_searcher_new": (i32, [C.c_void_p, C.c_void_p, u64, C.c_void_p, i32, P(C.c_void_p)]),
+    "isl_sharded_searcher_free": (None, [C.c_void_p]),
+    "isl_sharded_prepare": (i32, [C.c_void_p, u64, u64, u64]),
+    "isl_sharded_submit": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64, C.c_void_p, P(u64)]),
+    "isl_sharded_result": (i32, [C.c_void_p, u64, P(C.c_void_p), P(C.c_void_p), P(C.c_void_p), P(C.c_void_p),
+                                 P(SearchStatsC)]),
+    "isl_sharded_search_batch": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    "isl_sharded_flags": (i32, [C.c_void_p, P(u32)]),
     "isl_search_wait_stats": (i32, [C.c_void_p, u64, P(SearchStatsC)]),
     "isl_search_batch_async": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64, C.c_void_p,
                                      C.c_void_p, C.c_void_p, P(u64)]),
@@ -164,6 +178,9 @@ SIGNATURES = {
                                          C.c_void_p, i32, C.c_void_p]),
     "isl_pq_encode": (i32, [C.c_void_p, C.c_void_p, u64, u64, C.c_void_p, i32, C.c_void_p]),
 }
+
+# host all-gather callback of isl_shard_group_create_host: (user, send, recv, bytes) -> 0 on success
+SHARD_ALLGATHER_FN = C.CFUNCTYPE(i32, C.c_void_p, C.c_void_p, C.c_void_p, u64)
 
 _lib = None
 

@@ -19,7 +19,10 @@ constexpr int EPI_COSINE = 3, EPI_DOT = 4, EPI_EUCLIDEAN = 5;
 // which on the 4096 x 65536 x 4096 bf16 product was 11 % of the kernel.
 __device__ __forceinline__ float epi_cosine(float dot, float na, float nb) {
   const float nn = na * nb;
-  return nn == 0.0f ? 1.0f : 1.0f - dot * __builtin_amdgcn_rsqf(nn);
+  // v_rsq_f32 flushes a denormal input to zero (-> inf, NaN when dot == 0): below FLT_MIN take the
+  // reference's own form, norm = sqrt(na * nb), 1 - dot / norm (distance.rs:82-87), correctly rounded
+  if (nn < 1.17549435e-38f) return nn == 0.0f ? 1.0f : 1.0f - dot / sqrtf(nn);
+  return 1.0f - dot * __builtin_amdgcn_rsqf(nn);
 }
 __device__ __forceinline__ float epi_euclidean(float dot, float na, float nb) {
   const float v = na + nb - 2.0f * dot;

@@ -376,10 +376,10 @@ isl_status publish(isl::SearchWorkspace& ws, uint64_t nq, uint64_t k, hipStream_
 // Enqueues the kernels of one search on a claimed lane; every pointer is a device pointer.
 // warm = true: the same launches over zero queries (isl_index_prepare: loads the code objects and
 // brings the lane's stream up) -- nothing is read or written beyond the ticket words.
-isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const float* d_queries,
-                          uint64_t nq, uint64_t d, uint64_t k, uint64_t ef_in, uint64_t* d_ids,
-                          float* d_dist, uint32_t* d_count, hipStream_t user_stream,
-                          StreamMode mode, const TwoLevelCall* tl = nullptr, bool warm = false) {
+isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, const float* d_queries,
+                               uint64_t nq, uint64_t d, uint64_t k, uint64_t ef_in, uint64_t* d_ids,
+                               float* d_dist, uint32_t* d_count, hipStream_t user_stream,
+                               StreamMode mode, const TwoLevelCall* tl, bool warm) {
   if (nq > 0x7FFFFFFFull) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "too many queries");
   CallGeometry cg;
   ISL_TRY(call_geometry(idx, d, k, ef_in, tl, cg));
@@ -580,6 +580,28 @@ isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const 
   ws.k_inflight = k;
   ws.fast_inflight = use_fast;
   return ISL_OK;
+}
+
+// A failure part-way through an enqueue (a launch error, publish, a lane buffer that could not grow)
+// may leave kernels of this call on the stream: they are drained before the error goes back, because
+// the caller releases the lane next and the lane's next owner rewrites its pinned buffers / may
+// reallocate what those kernels still read.
+isl_status search_enqueue(const isl_index* idx, isl::SearchWorkspace& ws, const float* d_queries,
+                          uint64_t nq, uint64_t d, uint64_t k, uint64_t ef_in, uint64_t* d_ids,
+                          float* d_dist, uint32_t* d_count, hipStream_t user_stream,
+                          StreamMode mode, const TwoLevelCall* tl = nullptr, bool warm = false) {
+  const isl_status st = search_enqueue_impl(idx, ws, d_queries, nq, d, k, ef_in, d_ids, d_dist, d_count, user_stream,
+                                            mode, tl, warm);
+  if (st != ISL_OK) {
+    const isl::ErrorRecord keep = isl::last_error();
+    hipStream_t s = mode == StreamMode::USER ? user_stream : ws.stream;
+    if (mode == StreamMode::USER || s) (void)hipStreamSynchronize(s);
+    (void)hipGetLastError();
+    ws.ticket_clean = false;
+    ws.enqueued = false;
+    isl::last_error() = keep;
+  }
+  return st;
 }
 
 // counters of the most recent call this thread completed, per index (isl_search_last_stats)
@@ -861,6 +883,11 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
     ~RoundReset() { w.round_active = 0; w.round_listed = false; }
   } reset{ws};
   uint32_t* h_taken = ws.h_head + 15;  // (word 15 of the pinned ticket mirror is otherwise unused)
+  // Every query in flight advances by at least one hop per round, and a query makes at most a few
+  // times ef hops with new rows: the cap scales with the number of groups the batch is worked
+  // through in, so a 256-row cache (one query at a time) is not cut short and a bug still ends.
+  const uint64_t max_rounds = 64 + ((nq + max_active - 1) / max_active) * ((uint64_t)64 * cg0.ef + 4096);
+  uint32_t stalled = 0;
   for (;;) {
     ws.round_active = resumable ? active : 0u;
     ws.round_listed = listed;
@@ -888,11 +915,10 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
     } else if (!misses) {
       break;
     }
-    if (rounds > 200000)
-      return isl::fail(ISL_ERR_SEARCH, "Search error: the recompute provider's row cache (%llu rows) is too small "
-                       "for this batch (queries answered by the heap-exact or the two-level kernel re-run from "
-                       "their start and need the rows of their whole traversal resident)",
-                       (unsigned long long)idx->slab_rows);
+    if (rounds > max_rounds)
+      return isl::fail(ISL_ERR_SEARCH, "Search error: %llu recompute rounds without completing the batch (row cache "
+                       "%llu rows, %u queries in flight at a time)", (unsigned long long)rounds,
+                       (unsigned long long)idx->slab_rows, max_active);
     if (!misses) continue;  // only fresh queries to start
     if (misses > ws.miss_cap) misses = (uint32_t)ws.miss_cap;
     ISL_HIP(hipMemsetAsync(ws.uniq_count, 0, 4, st));
@@ -906,6 +932,15 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
     hipLaunchKernelGGL(copy_u32_kernel, dim3(1), dim3(64), 0, st, ws.ticket + 15, h_taken, (uint64_t)1);
     ISL_HIP(hipStreamSynchronize(st));
     const uint32_t take = *h_taken;
+    // no row could be placed although rows are missing: every slot is held by a hop of this round.  A
+    // resumable batch cannot get here (half the slab stays free by construction); a batch that re-runs
+    // its blocked queries from their start needs their whole traversal resident and never will be.
+    if (take == 0 && ++stalled >= (resumable ? 3u : 1u))
+      return isl::fail(ISL_ERR_SEARCH, "Search error: the recompute provider's row cache (%llu rows) is too small "
+                       "for this batch (queries answered by the heap-exact or the two-level kernel re-run from "
+                       "their start and need the rows of their whole traversal resident)",
+                       (unsigned long long)idx->slab_rows);
+    if (take) stalled = 0;
     ISL_TRY(isl::encoder_embed_nodes(idx->enc, idx->d_tokens, idx->d_lens, idx->tok_L, ws.uniq, take,
                                      idx->enc_normalize, idx->d_emb, idx->emb_stride, st, ws.uslots));
     const size_t lds = (size_t)TILE_ROWS * TILE_LD * 4 + 64;

@@ -5,15 +5,16 @@ cross-index merge (src/indexer/service.rs:775-801): every shard answers the whol
 batch in its own sub-graph, the per-shard top-k lists are concatenated in shard order,
 stable-sorted by distance and truncated to k.
 
-The exchange is ONE collective per batch: every rank's answers form one packed record
-(ids u64[nq][k] | distances f32[nq][k] | counts u32[nq], isl_shard_record_bytes) that the
-search kernels write in place, all-gathered in rank order (RCCL over xGMI when the process
-group's backend is "nccl"; "gloo" in the CPU tests and in the one-card rehearsal) and merged
-by isl_merge_topk_packed_async.  On the GPU path nothing in a step waits on the host: the
-collective and the merge are enqueued on a side stream behind an event of the search
-(isl_search_stream_wait), so they overlap the traversals of the batches submitted after it.
+The whole data path lives behind the C ABI (include/islands_amd.h, "multi-GPU"):
+isl_shard_group (RCCL communicator created from a unique id, or a host all-gather callback)
+and isl_sharded_searcher (shard search -> ONE all-gather of the packed records on a side
+stream behind a device event of the search -> merge kernel).  This module binds it and does
+the one thing the C ABI leaves to the host: carrying rank 0's 128-byte unique id to the other
+ranks, here through torch.distributed (any backend; plumbing only).
 
-torch.distributed is plumbing here; the search and the merge run in libislands_amd.so.
+ShardedSearcher keeps an injection path for CPU tests (local_search / merge callables over a
+gloo group): the sharding arithmetic and the record layout are shared with the C side
+(isl_shard_record_bytes) and checked against it.
 """
 from __future__ import annotations
 
@@ -24,6 +25,7 @@ import torch
 import torch.distributed as dist
 
 from . import CoreError, _check, _ffi
+from ._ffi import SearchStatsC
 
 
 def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
@@ -56,28 +58,95 @@ def device_merge(g_ids, g_dist, g_cnt, id_base, k: int, device_index: int):
     m_src = torch.zeros((nq, k), dtype=torch.int32, device=dev)
     m_cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
     base = np.ascontiguousarray(id_base, dtype=np.uint64)
+    # the contiguous copies must outlive the call (a temporary's block could be handed to the next copy)
+    gi, gd, gc = g_ids.contiguous(), g_dist.contiguous(), g_cnt.contiguous()
     _check(_ffi.lib().isl_merge_topk(
-        world, nq, kk, C.c_void_p(g_ids.contiguous().data_ptr()), C.c_void_p(g_dist.contiguous().data_ptr()),
-        C.c_void_p(g_cnt.contiguous().data_ptr()), base.ctypes.data_as(C.c_void_p), k,
+        world, nq, kk, C.c_void_p(gi.data_ptr()), C.c_void_p(gd.data_ptr()),
+        C.c_void_p(gc.data_ptr()), base.ctypes.data_as(C.c_void_p), k,
         C.c_void_p(m_ids.data_ptr()), C.c_void_p(m_dist.data_ptr()),
         C.c_void_p(m_src.data_ptr()), C.c_void_p(m_cnt.data_ptr()), 1, device_index, None))
+    del gi, gd, gc
     return m_ids, m_dist, m_src, m_cnt
+
+
+class ShardGroup:
+    """isl_shard_group: the communicator of the ranks.  transport "rccl": rank 0's unique id is
+    broadcast over the torch process group (whatever its backend), then every rank runs
+    ncclCommInitRank inside the library.  transport "host": the exchange is a blocking all-gather
+    over host memory through the torch process group (gloo) -- for ranks that share one card."""
+
+    def __init__(self, device_index: int, group=None, transport: str = "rccl"):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device_index = device_index
+        self.transport = transport
+        self._h = C.c_void_p()
+        self._cb = None
+        lib = _ffi.lib()
+        if transport == "rccl":
+            uid = (C.c_uint8 * 128)()
+            if self.rank == 0:
+                _check(lib.isl_shard_unique_id(uid))
+            if self.world > 1:
+                box = [bytes(uid)]
+                dist.broadcast_object_list(box, src=0, group=group)
+                uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            _check(lib.isl_shard_group_create(device_index, self.world, self.rank, uid, C.byref(self._h)))
+        elif transport == "host":
+            world, grp = self.world, group
+
+            def allgather(_user, send, recv, nbytes):
+                try:
+                    src = torch.frombuffer((C.c_uint8 * nbytes).from_address(send), dtype=torch.uint8)
+                    dst = torch.frombuffer((C.c_uint8 * (nbytes * world)).from_address(recv), dtype=torch.uint8)
+                    if world == 1:
+                        dst.copy_(src)
+                    else:
+                        dist.all_gather_into_tensor(dst, src.clone(), group=grp)
+                    return 0
+                except Exception:  # never let an exception cross the C frame
+                    return 1
+
+            self._cb = _ffi.SHARD_ALLGATHER_FN(allgather)
+            _check(lib.isl_shard_group_create_host(device_index, self.world, self.rank, self._cb, None,
+                                                   C.byref(self._h)))
+        else:
+            raise ValueError(transport)
+
+    def info(self) -> dict:
+        w, r, n, rc = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _check(_ffi.lib().isl_shard_group_info(self._h, C.byref(w), C.byref(r), C.byref(n), C.byref(rc)))
+        return {"world": w.value, "rank": r.value, "comm_ranks": n.value, "rccl": bool(rc.value)}
+
+    def close(self):
+        if self._h:
+            _ffi.lib().isl_shard_group_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ShardedSearcher:
     """Search over R shards, one per rank.
 
-    GPU path: `index` is this rank's LeannIndex over its node-id range (local ids).  submit()
-    enqueues search -> all-gather of the packed records -> merge without waiting for anything;
-    result() completes a submitted batch.  Up to `depth` batches may be in flight.
+    GPU path: `index` is this rank's LeannIndex over its node-id range (local ids); everything
+    runs in libislands_amd.so (isl_sharded_*).  submit() enqueues search -> all-gather of the packed
+    records -> merge without waiting for anything; result() completes a submitted batch.  Up to
+    `depth` batches may be in flight; `transport` "rccl" (default when the process group's backend
+    is nccl, and for a single rank) or "host" (gloo process groups: ranks sharing a card).
 
     Injection path (CPU tests): `local_search(queries, k, ef)` returns (ids [nq,k] int64,
     dist [nq,k] f32, count [nq] int32) with LOCAL ids and `merge(g_ids, g_dist, g_cnt, id_base, k)`
     turns the gathered [world, nq, k] lists into the global top-k; the sharding arithmetic, the
-    record layout and the single collective are the same code."""
+    record layout and the single collective are the same."""
 
     def __init__(self, n_total: int, local_search=None, merge=None, group=None, device="cpu", index=None,
-                 depth: int = 8):
+                 depth: int = 8, transport: str | None = None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -90,39 +159,43 @@ class ShardedSearcher:
         self.device = torch.device(device)
         self.index = index
         self.depth = depth
-        self._slots = {}      # (nq, k) -> list of per-slot buffers
-        self._inflight = {}   # handle -> slot state
-        self._next = 1
+        self._h = C.c_void_p()
+        self.shard_group = None
+        self._shapes = {}
         if index is not None:
-            self._side = torch.cuda.Stream(device=self.device)
-            self._d_base = torch.from_numpy(self.id_base.astype(np.int64)).to(self.device)
-            self._flags = torch.zeros(1, dtype=torch.int32, device=self.device)
+            if transport is None:
+                transport = "rccl" if (self.world == 1 or self.backend == "nccl") else "host"
+            dev_index = self.device.index or 0
+            if self.world > 1 or transport == "rccl":
+                self.shard_group = ShardGroup(dev_index, group, transport)
+            _check(_ffi.lib().isl_sharded_searcher_new(
+                index._h, self.shard_group._h if self.shard_group else None, n_total,
+                self.id_base.ctypes.data_as(C.c_void_p), depth, C.byref(self._h)))
 
-    # ------------------------------------------------------------------ one collective
+    # ------------------------------------------------------------------ injection path (CPU tests)
     def _all_gather_records(self, gathered: torch.Tensor, record: torch.Tensor):
         """gathered [world, B] <- every rank's record [B] (uint8), in rank order."""
         if self.world == 1:
             gathered[0].copy_(record)
-        elif self.backend == "nccl" or record.device.type == "cpu":
-            dist.all_gather_into_tensor(gathered.view(-1), record, group=self.group)
         else:
-            # rehearsal on a box with fewer cards than ranks: the ranks share a card and the
-            # exchange goes through host memory (gloo); synchronous by nature
-            torch.cuda.current_stream(record.device).synchronize()
-            host = torch.empty(gathered.shape, dtype=torch.uint8)
-            dist.all_gather_into_tensor(host.view(-1), record.cpu(), group=self.group)
-            gathered.copy_(host)
+            dist.all_gather_into_tensor(gathered.view(-1), record, group=self.group)
 
-    # ------------------------------------------------------------------ injection path
     def search_batch(self, queries, k: int, ef: int):
         if self.index is not None:
-            q = queries if torch.is_tensor(queries) else torch.as_tensor(np.ascontiguousarray(queries, np.float32))
-            q = q.to(self.device).contiguous()
-            h = self.submit(q, k, ef)
-            return self.result(h)
+            q = np.ascontiguousarray(queries.cpu().numpy() if torch.is_tensor(queries) else queries, np.float32)
+            nq, d = q.shape
+            ids = np.zeros((nq, k), np.uint64)
+            dd = np.zeros((nq, k), np.float32)
+            src = np.zeros((nq, k), np.uint32)
+            cnt = np.zeros(nq, np.uint32)
+            _check(_ffi.lib().isl_sharded_search_batch(
+                self._h, q.ctypes.data_as(C.c_void_p), nq, d, k, ef, ids.ctypes.data_as(C.c_void_p),
+                dd.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)))
+            return ids, dd, src, cnt
         ids, dd, cnt = self.local_search(queries, k, ef)
         nq = ids.shape[0]
         B = record_bytes(nq, k)
+        assert B == int(_ffi.lib().isl_shard_record_bytes(nq, k))
         rec = torch.zeros(B, dtype=torch.uint8, device=self.device)
         r_ids, r_dd, r_cnt = record_views(rec, nq, k)
         r_ids.copy_(ids); r_dd.copy_(dd); r_cnt.copy_(cnt)
@@ -131,79 +204,71 @@ class ShardedSearcher:
         g_ids, g_dd, g_cnt = record_views(gathered, nq, k)
         return self.merge(g_ids, g_dd, g_cnt, self.id_base, k)
 
-    # ------------------------------------------------------------------ GPU path
-    def _slot(self, nq: int, k: int):
-        pool = self._slots.setdefault((nq, k), [])
-        for s in pool:
-            if not s["busy"]:
-                return s
-        if len(pool) >= self.depth:
-            raise CoreError(11, f"Search error: {self.depth} sharded batches already in flight; call result() first")
-        B = record_bytes(nq, k)
-        dev = self.device
-        s = {"busy": False, "B": B,
-             "rec": torch.zeros(B, dtype=torch.uint8, device=dev),
-             "gath": torch.zeros((self.world, B), dtype=torch.uint8, device=dev),
-             "ids": torch.zeros((nq, k), dtype=torch.int64, device=dev),
-             "dist": torch.zeros((nq, k), dtype=torch.float32, device=dev),
-             "src": torch.zeros((nq, k), dtype=torch.int32, device=dev),
-             "cnt": torch.zeros(nq, dtype=torch.int32, device=dev),
-             "done": torch.cuda.Event()}
-        pool.append(s)
-        return s
-
+    # ------------------------------------------------------------------ GPU path (C ABI)
     def prepare(self, nq: int, k: int, ef: int):
-        """Buffers for `depth` batches in flight and the index's lanes, ahead of time."""
-        self.index.prepare(nq, ef, k, min(self.depth, 16))
-        made = [self._slot(nq, k) for _ in range(self.depth)]
-        for s in made:
-            s["busy"] = True
-        for s in made:
-            s["busy"] = False
+        """isl_sharded_prepare: buffers for `depth` batches in flight, the index's lanes, and (RCCL) the
+        communicator's first collective.  Collective over the ranks."""
+        _check(_ffi.lib().isl_sharded_prepare(self._h, nq, k, ef))
         return self
 
-    def submit(self, d_queries: torch.Tensor, k: int, ef: int) -> int:
-        """Enqueue one batch: search on a lane of the index, then -- on the side stream, behind the
-        search's event -- the all-gather of the records and the merge.  Returns a handle."""
+    def submit(self, d_queries: torch.Tensor, k: int, ef: int, stream: int = 0) -> int:
+        """isl_sharded_submit: enqueue one batch (search, all-gather of the records, merge)."""
         nq, d = d_queries.shape
-        s = self._slot(nq, k)
-        rec = s["rec"]
-        base = rec.data_ptr()
-        tok = self.index.search_batch_device_async(d_queries.data_ptr(), nq, d, k, ef, base, base + nq * k * 8,
-                                                   base + nq * k * 12)
-        lib = _ffi.lib()
-        side = self._side
-        _check(lib.isl_search_stream_wait(self.index._h, tok, C.c_void_p(side.cuda_stream)))
-        with torch.cuda.stream(side):
-            self._all_gather_records(s["gath"], rec)
-            _check(lib.isl_merge_topk_packed_async(
-                self.world, nq, k, C.c_void_p(s["gath"].data_ptr()), s["B"], C.c_void_p(self._d_base.data_ptr()), k,
-                C.c_void_p(s["ids"].data_ptr()), C.c_void_p(s["dist"].data_ptr()), C.c_void_p(s["src"].data_ptr()),
-                C.c_void_p(s["cnt"].data_ptr()), C.c_void_p(self._flags.data_ptr()), self.device.index or 0,
-                C.c_void_p(side.cuda_stream)))
-            s["done"].record(side)
-        s["busy"] = True
-        h = self._next
-        self._next += 1
-        self._inflight[h] = (s, tok)
-        return h
+        h = C.c_uint64()
+        _check(_ffi.lib().isl_sharded_submit(self._h, C.c_void_p(d_queries.data_ptr()), nq, d, k, ef,
+                                             C.c_void_p(stream), C.byref(h)))
+        self._shapes[int(h.value)] = (nq, k)
+        return int(h.value)
 
     def result(self, handle: int, with_stats: bool = False):
-        """Completes a submitted batch: (ids [nq,k] int64 global, dist, src shard, count) on the
-        device -- valid until the slot is reused `depth` submissions later -- [+ search counters]."""
-        s, tok = self._inflight.pop(handle)
-        try:
-            st = self.index.wait_stats(tok)      # per-query failures of this rank's shard surface here
-            s["done"].synchronize()
-        finally:
-            s["busy"] = False
-        out = (s["ids"], s["dist"], s["src"], s["cnt"])
-        return (out, st) if with_stats else out
+        """isl_sharded_result: (ids [nq,k] int64 global, dist, src shard, count) as tensors over the
+        library's device buffers -- valid until `depth` further batches have been submitted --
+        [+ this rank's search counters]."""
+        nq, k = self._shapes.pop(handle)
+        p = [C.c_void_p() for _ in range(4)]
+        st = SearchStatsC()
+        _check(_ffi.lib().isl_sharded_result(self._h, handle, C.byref(p[0]), C.byref(p[1]), C.byref(p[2]),
+                                             C.byref(p[3]), C.byref(st)))
+        out = (_device_view(p[0].value, (nq, k), torch.int64, self.device),
+               _device_view(p[1].value, (nq, k), torch.float32, self.device),
+               _device_view(p[2].value, (nq, k), torch.int32, self.device),
+               _device_view(p[3].value, (nq,), torch.int32, self.device))
+        if with_stats:
+            return out, {f: getattr(st, f) for f, _ in SearchStatsC._fields_}
+        return out
 
     def check_flags(self):
         """NaN scores make the reference's merge panic (search.rs:231); lists must be ascending."""
-        f = int(self._flags.item())
-        if f & 1:
+        f = C.c_uint32()
+        _check(_ffi.lib().isl_sharded_flags(self._h, C.byref(f)))
+        if f.value & 1:
             raise CoreError(11, "Search error: NaN score in merge (the reference panics here)")
-        if f & 2:
+        if f.value & 2:
             raise CoreError(14, "per-list scores must be ascending")
+
+    def close(self):
+        if self._h:
+            _ffi.lib().isl_sharded_searcher_free(self._h)
+            self._h = C.c_void_p()
+        if self.shard_group is not None:
+            self.shard_group.close()
+            self.shard_group = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _DevArray:
+    """__cuda_array_interface__ over a raw device pointer owned by the library."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def _device_view(ptr: int, shape, dtype, device) -> torch.Tensor:
+    typestr = {torch.int64: "<i8", torch.float32: "<f4", torch.int32: "<i4"}[dtype]
+    return torch.as_tensor(_DevArray(ptr, shape, typestr), device=device)

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, missing
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
-    assert lib.isl_abi_version() == 2
+    assert lib.isl_abi_version() == 3
 
 
 def test_config_presets():  # leann.rs:1091-1143

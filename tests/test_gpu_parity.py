@@ -571,3 +571,23 @@ def test_distance_matrix_bf16_matches_batch_calculate(orc, metric, nq, n, d):
     with pytest.raises(ia.CoreError) as e:
         ia.distance_matrix_bf16(metric, qb[:, :40], rb[:, :40])
     assert e.value.kind == "Unsupported"
+
+
+def test_distance_matrix_cosine_with_tiny_norms(orc):
+    """Rows whose squared norms multiply to a denormal (or to zero): the 1-ulp rsq of the GEMM epilogue
+    flushes such an input to zero -- those elements must take the reference's own form,
+    1 - dot / sqrt(na * nb), and 1.0 when the product is exactly zero (distance.rs:82-87)."""
+    d = 32
+    rng = np.random.default_rng(5)
+    rows = rng.standard_normal((40, d)).astype(np.float32)
+    rows[3] *= np.float32(1e-12)
+    rows[7] *= np.float32(3e-11)
+    rows[9] = 0.0
+    q = rng.standard_normal((6, d)).astype(np.float32)
+    q[1] *= np.float32(1e-9)    # |q|^2 |r|^2 ~ 1e-18 * 1e-24 * d^2: below FLT_MIN, above zero
+    q[2] *= np.float32(1e-12)   # ... and underflowing to exactly zero for the smallest rows
+    got = ia.distance_matrix(ia.DistanceMetric.Cosine, q, rows)
+    assert np.isfinite(got).all()
+    for i in range(q.shape[0]):
+        want = orc.batch_distance(orc.COSINE, q[i], rows)
+        assert np.abs(got[i] - want).max() < 1e-5, (i, np.abs(got[i] - want).argmax())

@@ -106,3 +106,52 @@ def test_two_ranks_one_card_equal_multi_index_searcher(tmp_path):
             assert ids_b[qi, :n].astype(np.uint64).tolist() == ids.tolist(), (b, qi)
             assert dd_b[qi, :n].view(np.uint32).tolist() == sc.view(np.uint32).tolist()
             assert src_b[qi, :n].tolist() == src.tolist()
+
+
+def test_single_rank_rccl_group_and_host_entry():
+    """The RCCL transport with the one rank this box has: ncclCommInitRank from a unique id, the
+    communicator's all-gather of the packed record on the side stream, merge -- through
+    isl_sharded_submit / _result and through the host-buffer entry isl_sharded_search_batch.
+    Expected = the oracle's search of the one shard (MultiIndexSearcher over a single index)."""
+    world, n_total, d, k, ef = 1, 2500, 32, 6, 48
+    orc, x, shards, qs = _shards(n_total, d, world)
+    import islands_amd as ia
+    from islands_amd.sharded import ShardedSearcher
+
+    lo, xs, csr = shards[0]
+    g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels, entry_point=0,
+                    num_nodes=csr.num_nodes, degree_counts=csr.degree_counts)
+    idx = ia.LeannIndex.from_csr(g, dimension=d).upload(0)
+    idx.set_embeddings(xs)
+    s = ShardedSearcher(n_total, index=idx, device="cuda:0", depth=2, transport="rccl")
+    info = s.shard_group.info()
+    assert info == {"world": 1, "rank": 0, "comm_ranks": 1, "rccl": True}
+    s.prepare(qs[0].shape[0], k, ef)
+    dq = [torch.from_numpy(q).cuda() for q in qs]
+    got, handles = [], []
+    for q in dq:
+        handles.append(s.submit(q, k, ef))
+        if len(handles) == 2:
+            (ids, dd, src, cnt), st = s.result(handles.pop(0), with_stats=True)
+            assert st["allocations"] == 0 and st["queries"] == q.shape[0]
+            got.append((ids.cpu().numpy().copy(), dd.cpu().numpy().copy(), cnt.cpu().numpy().copy()))
+    while handles:
+        ids, dd, src, cnt = s.result(handles.pop(0))
+        got.append((ids.cpu().numpy().copy(), dd.cpu().numpy().copy(), cnt.cpu().numpy().copy()))
+    s.check_flags()
+    h_ids, h_dd, h_src, h_cnt = s.search_batch(qs[0], k, ef)
+    for b, q in enumerate(qs):
+        for qi in range(q.shape[0]):
+            r = orc.leann_search(csr, xs, q[qi], k, ef)
+            n = int(got[b][2][qi])
+            assert n == r.ids.size
+            assert got[b][0][qi, :n].astype(np.uint64).tolist() == r.ids.tolist()
+            assert got[b][1][qi, :n].view(np.uint32).tolist() == r.dist.view(np.uint32).tolist()
+            if b == 0:
+                assert h_ids[qi, :n].tolist() == r.ids.tolist() and int(h_cnt[qi]) == n
+                assert h_dd[qi, :n].view(np.uint32).tolist() == r.dist.view(np.uint32).tolist()
+                assert (h_src[qi, :n] == 0).all()
+    # a handle is good once
+    with pytest.raises(ia.CoreError):
+        s.result(12345)
+    s.close()

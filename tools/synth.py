@@ -86,11 +86,20 @@ def make_rows(n_total: int, d: int, start: int, count: int, seed: int = 42,
     return out
 
 
-def make_uniform(count: int, d: int, seed: int, device="cuda:0") -> torch.Tensor:
-    """Reference-style data: i.i.d. uniform [-1, 1) (benches/hnsw_benchmarks.rs:9-14)."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    return torch.rand((count, d), generator=g, device=device, dtype=torch.float32) * 2 - 1
+def make_uniform(count: int, d: int, seed: int, device="cuda:0", start: int = 0) -> torch.Tensor:
+    """Reference-style data: i.i.d. uniform [-1, 1) (benches/hnsw_benchmarks.rs:9-14), rows
+    [start, start + count) of the stream `seed` names.  Every chunk of 65536 rows has its own seed, so
+    a shard generates exactly its rows and nothing else (config 4: 100M rows never exist in one place)."""
+    dev = torch.device(device)
+    out = torch.empty((count, d), device=dev, dtype=torch.float32)
+    g = torch.Generator(device=dev)
+    for c in range(start // CHUNK, (start + count + CHUNK - 1) // CHUNK):
+        lo, hi = c * CHUNK, (c + 1) * CHUNK
+        g.manual_seed(seed * 1000003 + c * 7919 + 11)
+        x = torch.rand((CHUNK, d), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+        a, b = max(lo, start), min(hi, start + count)
+        out[a - start:b - start] = x[a - lo:b - lo]
+    return out
 
 
 # ------------------------------------------------------------------ ground truth
