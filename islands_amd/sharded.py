@@ -224,7 +224,7 @@ class ShardedSearcher:
         """isl_sharded_result: (ids [nq,k] int64 global, dist, src shard, count) as tensors over the
         library's device buffers -- valid until `depth` further batches have been submitted --
         [+ this rank's search counters]."""
-        nq, k = self._shapes.pop(handle)
+        nq, k = self._shapes.pop(handle, (0, 0))  # (an unknown handle is the library's error to raise)
         p = [C.c_void_p() for _ in range(4)]
         st = SearchStatsC()
         _check(_ffi.lib().isl_sharded_result(self._h, handle, C.byref(p[0]), C.byref(p[1]), C.byref(p[2]),

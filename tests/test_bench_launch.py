@@ -2,7 +2,10 @@
 the command, round 2: --gpus was parsed and never used).  CPU part: the launch plumbing in --dry-run
 mode (rendezvous on 127.0.0.1, one all-gather of a packed record over gloo, the JSON line passed
 through by the parent, which never touches the GPU).  GPU part: the real two-rank run on one card
-(ISL_BENCH_BACKEND=gloo rehearsal: shard search, exchange and merge inside libislands_amd.so)."""
+(ISL_BENCH_BACKEND=gloo rehearsal: shard search, exchange and merge inside libislands_amd.so).
+(80000 nodes, not fewer: the harness's graph over a 10000-row shard of 20 half-clusters reaches a
+local recall of 0.56 -- a property of tools/synth.py at that size, measured per shard with no
+exchange involved -- while 40000-row shards reach 1.0.)"""
 import json
 import os
 import subprocess
@@ -38,7 +41,7 @@ def test_gpus_flag_launches_the_ranks_itself_dry_run():
 @pytest.mark.gpu
 @pytest.mark.timeout(1200)
 def test_two_ranks_on_one_card_without_a_launcher():
-    res = _run(["--gpus", "2", "--nodes", "20000", "--nq", "64", "--steps", "4", "--warmup", "2", "--pipeline", "3",
+    res = _run(["--gpus", "2", "--nodes", "80000", "--nq", "64", "--steps", "4", "--warmup", "2", "--pipeline", "3",
                 "--no-cpu-baseline", "--no-replica", "--no-traffic"], {"ISL_BENCH_BACKEND": "gloo"})
     assert res["n_gpus"] == 2
     ex = res["config"]["exchange"]
