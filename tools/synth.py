@@ -165,6 +165,24 @@ def _trace(msg):
         print(f"[synth] {msg}", file=sys.stderr, flush=True)
 
 
+# Every tensor the harness gathers or materialises per chunk is bounded in BYTES, computed from the
+# element size of what is actually allocated (float32 operands: 4 bytes whatever the rows' storage
+# type).  Round 2 lost a box to "Memory access fault by GPU" inside this builder on 1M x 4096 bf16 rows
+# (gpurun_out/r02_config5_1m.err) with per-chunk tensors of 2^30 bf16 elements = 2 GiB less 512 KiB
+# ([2730, 96, 4096] in _diversify: the row gather and the two batched bf16 GEMMs over it) after a
+# first bound, on the element count, had already excluded 2^31 elements; the run passed once the
+# operands were float32 AND the count was halved.  Which of the two mattered was never isolated (and
+# must not be, by provoking the fault again): the bound below keeps every such tensor at or under
+# 1 GiB -- a factor of two away from 2^31 in bytes and at least four in elements -- so that no 32-bit
+# byte or element offset inside torch / rocBLAS / hipBLASLt kernels can come near its limit.
+_CHUNK_BYTES = 1 << 30
+
+
+def _rows_within(bytes_per_row: int, want: int, floor: int = 64) -> int:
+    """Rows per chunk such that rows * bytes_per_row <= _CHUNK_BYTES (at least `floor`, at most `want`)."""
+    return max(floor, min(want, _CHUNK_BYTES // max(1, bytes_per_row)))
+
+
 # dtype of the k-means / bucket ASSIGNMENT GEMMs (build_graph(precise=True) switches to float32:
 # embeddings with a large common component -- a randomly initialised encoder's -- differ from each
 # other only past bfloat16's 8 bits)
@@ -172,7 +190,7 @@ _ASSIGN_DTYPE = torch.bfloat16
 
 
 @torch.no_grad()
-def _knn_in_buckets(x, member_ids, bucket_off, k, mem_budget=1.5e9):
+def _knn_in_buckets(x, member_ids, bucket_off, k, mem_budget=1.0e9):
     """For every (point, bucket) membership: the k nearest OTHER members of that bucket.
     member_ids: int64 [P] point ids grouped by bucket; bucket_off: int64 [B+1].
     Returns (nbr_ids int64 [P, k] (-1 = none), nbr_sim f32 [P, k])."""
@@ -252,7 +270,7 @@ def _knn_exact(x, ids, k, chunk=4096):
 def _medoids(x, ids, C, chunk=1 << 18):
     """For every centroid the most similar point among `ids` (global ids, duplicates removed)."""
     dev = x.device
-    chunk = max(1024, min(chunk, (1 << 29) // x.shape[1]))
+    chunk = _rows_within(x.shape[1] * 4, chunk, 1024)  # x[sub] widened to at most float32
     k = C.shape[0]
     best_s = torch.full((k,), -3.0, device=dev)
     best_i = torch.zeros(k, dtype=torch.int64, device=dev)
@@ -275,7 +293,7 @@ def _lloyd_centroids(x, n_cent, iters=3, seed=11, chunk=1 << 18, ids=None):
     if ids is not None:
         x = x[ids]
     n, d = x.shape
-    chunk = max(1024, min(chunk, (1 << 29) // d))
+    chunk = _rows_within(d * 4, chunk, 1024)  # xb[order].float(): d * 4 bytes per row
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     C = x[torch.randperm(n, generator=g, device=dev)[:n_cent]].float().clone()  # (x may be bf16 rows)
@@ -312,7 +330,7 @@ def _knn_subset(x, ids, k, centroids=None, assign_chunk=1 << 18, exact_limit=400
     if n <= exact_limit or centroids is None:
         return _knn_exact(x, ids, min(k, n - 1))
     C = centroids
-    assign_chunk = max(1024, min(assign_chunk, (1 << 29) // x.shape[1]))
+    assign_chunk = _rows_within(x.shape[1] * 4, assign_chunk, 1024)
     a1 = torch.empty(n, dtype=torch.int64, device=dev)
     a2 = torch.empty(n, dtype=torch.int64, device=dev)
     Ch = C.to(_ASSIGN_DTYPE)
@@ -355,9 +373,10 @@ def _diversify(x, ids, cand, m, chunk=8192):
     dev = x.device
     n, K = cand.shape
     out = torch.full((n, m), -1, dtype=torch.int64, device=dev)
-    # the gathered candidate rows [chunk, K, d] stay below 2^30 elements (d = 4096: a tensor past
-    # 2^31 elements took the GPU down with a memory access fault in the gather / batched GEMM)
-    chunk = max(64, min(chunk, (1 << 29) // (K * x.shape[1])))
+    # the gathered candidate rows Cv [chunk, K, d] as float32 stay within _CHUNK_BYTES (see there: the
+    # recorded GPU fault sat in this function's neighbourhood -- chunk = 2730 at K = 96, d = 4096 made
+    # Cv 2,146,959,360 bytes of bf16, 512 KiB short of 2^31, gathered with x[c] and fed to two bmm's)
+    chunk = _rows_within(K * x.shape[1] * 4, chunk, 64)
     for s0 in range(0, n, chunk):
         c = cand[s0:s0 + chunk]
         valid = c >= 0
@@ -390,7 +409,7 @@ def _diversify(x, ids, cand, m, chunk=8192):
 def _nearest_parent(x, child_ids, parent_ids, npar=2, chunk=1 << 16):
     """Indices (into parent_ids) of the npar most similar parents of every child: [n, npar]."""
     P = x[parent_ids].float()
-    chunk = max(1024, min(chunk, (1 << 29) // x.shape[1]))
+    chunk = _rows_within(x.shape[1] * 4, chunk, 1024)
     npar = min(npar, parent_ids.numel())
     out = torch.empty((child_ids.numel(), npar), dtype=torch.int64, device=x.device)
     for s0 in range(0, child_ids.numel(), chunk):
@@ -433,7 +452,8 @@ def _build_graph(x: torch.Tensor, m0: int = 60, k0: int = 28, k_upper: int = 20,
     # medoids of a spherical k-means over the level below, so that every region of the data
     # owns a node at every scale (a purely random sample leaves ~1/e of the natural
     # clusters without a representative two levels up, and those become unreachable).
-    exact_limit = min(400_000, (1 << 29) // x.shape[1] * 2)  # the gathered rows of an exact kNN stay below 2^30 elements
+    # the float32 copy x[ids] of an exact kNN stays within 2^30 bytes (d = 768: 349525 rows, 4096: 65536)
+    exact_limit = min(400_000, _CHUNK_BYTES // (x.shape[1] * 4))
     all_ids = torch.arange(n, device=dev)
     perm = torch.randperm(n, generator=g, device=dev)
     cent = None
@@ -567,7 +587,7 @@ def train_pq(x: torch.Tensor, m: int, K: int = 256, iters: int = 6, seed: int = 
     dsub = d // m
     g = torch.Generator(device=x.device)
     g.manual_seed(seed)
-    sample = max(4096, min(sample, (1 << 29) // d))
+    sample = _rows_within(d * 4, sample, 4096)
     pick = torch.randperm(n, generator=g, device=x.device)[:min(sample, n)]
     xs = x[pick].float()  # (x may be bf16 rows)
     cb = torch.empty((m, K, dsub), dtype=torch.float32, device=x.device)
