@@ -245,7 +245,10 @@ isl_status isl_search_batch_device(const isl_index* idx, const float* d_queries,
  * the work already enqueued on `stream`) and returns at once; up to 16 searches may be in
  * flight, so consecutive batches overlap and the slowest queries of one batch no longer idle
  * the chip.  Outputs are valid and the per-query status is reported once isl_search_wait
- * returns for *token (token 0 = the call was answered immediately). */
+ * returns for *token (token 0 = the call was answered immediately).  An index with the recompute
+ * provider is accepted too (this form and isl_search_batch_async): the provider works through the
+ * batch in rounds -- search, encode what was missed, resume -- on a host thread of the library's,
+ * one such call at a time per index; isl_search_stream_wait then waits on the host. */
 isl_status isl_search_batch_device_async(const isl_index* idx, const float* d_queries, uint64_t nq,
                                          uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_out_ids,
                                          float* d_out_dist, uint32_t* d_out_count, void* stream,
@@ -556,6 +559,14 @@ isl_status isl_search_two_level_batch_device(const isl_index* idx, const float* 
                                              uint64_t d, uint64_t k, uint64_t ef, float rerank_ratio,
                                              uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count,
                                              void* stream);
+/* Asynchronous form (see isl_search_batch_device_async): up to 16 calls in flight on the index's
+ * lanes, completed with isl_search_wait[_stats](*token).  The call runs on a host thread of the
+ * library's (a query whose queue window was too small is re-run with a larger one before the call
+ * completes), so isl_search_stream_wait for such a token waits on the host. */
+isl_status isl_search_two_level_batch_device_async(const isl_index* idx, const float* d_queries, uint64_t nq,
+                                                   uint64_t d, uint64_t k, uint64_t ef, float rerank_ratio,
+                                                   uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count,
+                                                   void* stream, uint64_t* token);
 
 #ifdef __cplusplus
 }

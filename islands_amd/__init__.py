@@ -545,6 +545,17 @@ class LeannIndex:
             C.c_void_p(d_ids_ptr), C.c_void_p(d_dist_ptr), C.c_void_p(d_count_ptr),
             C.c_void_p(stream)))
 
+    def search_two_level_batch_device_async(self, d_queries_ptr: int, nq: int, d: int, k: int, ef: int,
+                                            rerank_ratio: float, d_ids_ptr: int, d_dist_ptr: int,
+                                            d_count_ptr: int, stream: int = 0) -> int:
+        """isl_search_two_level_batch_device_async: returns a token for wait() / wait_stats()."""
+        tok = C.c_uint64()
+        _check(_ffi.lib().isl_search_two_level_batch_device_async(
+            self._h, C.c_void_p(d_queries_ptr), nq, d, k, ef, C.c_float(rerank_ratio),
+            C.c_void_p(d_ids_ptr), C.c_void_p(d_dist_ptr), C.c_void_p(d_count_ptr),
+            C.c_void_p(stream), C.byref(tok)))
+        return int(tok.value)
+
     def search_batch_device(self, d_queries_ptr: int, nq: int, d: int, k: int, ef: int,
                             d_ids_ptr: int, d_dist_ptr: int, d_count_ptr: int, stream: int = 0):
         _check(_ffi.lib().isl_search_batch_device(

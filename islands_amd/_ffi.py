@@ -96,6 +96,9 @@ SIGNATURES = {
     "isl_search_two_level_batch_device": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64,
                                                 C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_void_p]),
+    "isl_search_two_level_batch_device_async": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64,
+                                                      C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p, P(u64)]),
     "isl_search_batch_device": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "isl_search_batch_device_async": (i32, [C.c_void_p, C.c_void_p, u64, u64, u64, u64, C.c_void_p,

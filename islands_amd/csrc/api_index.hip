@@ -268,6 +268,7 @@ void isl_index_free(isl_index* idx) {
   if (!idx) return;
   if (idx->device >= 0) {
     (void)hipSetDevice(idx->device);
+    join_lane_workers(idx);
     for (auto& w : idx->ws)
       if (w.busy && w.st_inflight) (void)hipStreamSynchronize(w.st_inflight);
     if (idx->ell_owned) { (void)hipFree(idx->d_ell); (void)hipFree(idx->d_ell_deg); }

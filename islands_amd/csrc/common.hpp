@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/islands_amd.h"
@@ -124,6 +125,16 @@ struct SearchWorkspace {
   // two-level search: per-query PQ distance tables [nq][m * K]
   float* tl_tables = nullptr;
   uint64_t tl_tables_cap = 0;
+  bool tl_tables_built = false;  // ... of the call in flight (its later rounds / retries reuse them)
+  uint32_t retry_count = 0;      // two-level search: queries re-run alone with a larger queue window (listed in qlist)
+  // Asynchronous calls that cannot be split into "enqueue now, finish at wait" -- the rounds of the
+  // recompute provider, the two-level search with its per-query retries -- run their synchronous form
+  // on a host thread of their own; whoever waits for the token joins it and takes its status and
+  // error record over.
+  std::thread* worker = nullptr;
+  bool threaded = false;         // the call in flight runs (or ran) on `worker`
+  isl_status worker_status = ISL_OK;
+  ErrorRecord worker_error;
   // device / pinned-host allocations, stream and event creations made for this lane so far: a
   // call's share of it is reported in isl_search_stats::allocations (0 after isl_index_prepare)
   uint64_t alloc_events = 0;
@@ -246,6 +257,8 @@ void free_exact_pool(ExactPool& pool);
 // true while a search is in flight on any lane (call under idx->mu): provider / PQ setters and
 // isl_index_free must not free tables such a search reads
 bool any_lane_busy(const isl_index* idx);
+// joins the host threads of asynchronous calls still running on the index's lanes (isl_index_free)
+void join_lane_workers(const isl_index* idx);
 // Builds the padded adjacency (64 ids per node + degrees) the traversal reads; under idx->mu.
 isl_status ensure_padded_adjacency(isl_index* idx);
 }  // namespace isl

@@ -61,9 +61,11 @@ struct TwoLevelCall {
   float ratio;
   uint32_t window_scale = 1;  // the window grows 4x per retry after a query outgrew it
 };
-size_t two_level_lds(uint32_t hbits, uint32_t wcap, uint32_t ef, uint32_t d) {
-  return ((size_t)4 << hbits) + (size_t)(wcap + 64) * 8 + (size_t)((ef + 63) / 64 * 64 + 64) * 8 + 64 * 8 +
-         64 * 4 + (size_t)((d + 3) / 4 * 4) * 4 + ((d & 15) ? 64 : 0);
+// qbytes = 2: the instantiation that keeps a bf16-valued query as bf16 (bf16 rows)
+size_t two_level_lds(uint32_t hbits, uint32_t wcap, uint32_t ef, uint32_t d, uint32_t qbytes = 4) {
+  return ((size_t)4 << hbits) + (size_t)(wcap + 64) * 8 + (size_t)tl_res_entries(ef) * 8 + 64 * 8 +
+         128 * 4 + (size_t)kTlLdsWords * 4 +
+         (qbytes == 2 ? (size_t)((d + 7) / 8 * 8) * 2 + 64 : (size_t)((d + 3) / 4 * 4) * 4 + ((d & 15) ? 64 : 0));
 }
 
 __global__ void fill_u32_kernel(uint32_t* p, uint64_t n, uint32_t v) {
@@ -311,6 +313,9 @@ struct CallGeometry {
   uint32_t plog_cap = 0;
   uint32_t tl_wcap = 0;
   size_t tl_lds = 0;
+  uint32_t tl_hbits_q = 0;   // the bf16-query instantiation: visited-table bits, LDS, resident waves
+  size_t tl_lds_q = 0;
+  uint32_t tl_slots_q = 0;
 };
 
 isl_status call_geometry(const isl_index* idx, uint64_t d, uint64_t k, uint64_t ef_in, const TwoLevelCall* tl,
@@ -329,11 +334,14 @@ isl_status call_geometry(const isl_index* idx, uint64_t d, uint64_t k, uint64_t 
   uint32_t per_cu = (uint32_t)std::min<size_t>(cu_cap, (160 * 1024) / g.fg.lds);
   if (per_cu == 0) g.use_fast = false;
   if (tl) {
-    // window of the approximate queue: ceil(a * |AQ|) must stay inside it; |AQ| is bounded by the
-    // node count and, in practice, by a few dozen times ef
+    // Window of the approximate queue: ceil(a * |AQ|) must stay inside it.  |AQ| is bounded by the
+    // node count and runs at about 10 x ef (1235 at ef = 128 on the 10M-node bench graph); 20 x ef
+    // covers the long queries, and one that outgrows it is re-run alone with four times the window
+    // (never answered differently).  The window is most of a wave's LDS: round 2 sized it for
+    // 32 x ef and ran 3 waves per CU at d = 4096.
     g.use_fast = false;
     const float a = tl->ratio > 0.0f ? std::min(tl->ratio, 1.0f) : 0.0f;
-    const double bound = (double)std::min<uint64_t>(idx->ncodes, (uint64_t)32 * ef * tl->window_scale);
+    const double bound = (double)std::min<uint64_t>(idx->ncodes, (uint64_t)20 * ef * tl->window_scale);
     const uint64_t want = (uint64_t)(a * bound) + 64;
     g.tl_wcap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((want + 63) / 64 * 64, 256), 16384);
     while (g.tl_wcap > 256 && two_level_lds(g.fg.hbits, g.tl_wcap, ef, (uint32_t)d) > 160 * 1024) g.tl_wcap -= 64;
@@ -342,6 +350,10 @@ isl_status call_geometry(const isl_index* idx, uint64_t d, uint64_t k, uint64_t 
       return isl::fail(ISL_ERR_UNSUPPORTED, "two-level search: ef = %u, d = %llu do not fit the LDS", ef,
                        (unsigned long long)d);
     per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(cu_cap, (160 * 1024) / g.tl_lds));
+    // bf16 rows: the queries whose elements are bf16 values keep their query as bf16 in LDS
+    g.tl_hbits_q = fast_geometry(ef, (uint32_t)d, 2).hbits;
+    g.tl_lds_q = two_level_lds(g.tl_hbits_q, g.tl_wcap, ef, (uint32_t)d, 2);
+    g.tl_slots_q = (uint32_t)ncu * (uint32_t)std::max<size_t>(1, std::min<size_t>(cu_cap, (160 * 1024) / g.tl_lds_q));
   }
   g.slots = std::max<uint32_t>(1, (uint32_t)ncu * std::max<uint32_t>(per_cu, 1));
   g.plog_cap = push_log_cap(ef);
@@ -389,7 +401,12 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
   const uint32_t slots = cg.slots, plog_cap = cg.plog_cap;
   // searches over the recompute provider park and resume on the fast kernel (f32 rows; the
   // two-level and heap-exact kernels re-run a blocked query from its start instead)
-  const bool resume = !warm && ws.round_active != 0 && use_fast && !tl;
+  const bool resume = !warm && ws.round_active != 0 && (tl || use_fast);
+  // two-level search over bf16 rows: first the instantiation that keeps a bf16-valued query as bf16
+  // in LDS, then the float32-query one over the queries it passed on (not in a retry's list mode)
+  static const bool no_tl_qh = getenv("ISL_NO_TL_QH") != nullptr;  // A/B switch for measurements
+  const bool tl_qh = tl && !warm && !resume && idx->d_emb16 && ws.retry_count == 0 && !no_tl_qh &&
+                     cg.tl_hbits_q == cg.fg.hbits;
   // bf16 rows: first the kernel that keeps the query as bf16 in LDS (half the LDS per wave, more
   // waves per CU), then the float32-query kernel over the queries that one passed on
   static const bool no_qh = getenv("ISL_NO_QH") != nullptr;  // A/B switch for measurements
@@ -405,7 +422,8 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
   // another wave
   if (!warm)
     ISL_TRY(prepare_workspace(ws, (uint32_t)nq,
-                              (uint32_t)(idx->recompute ? nq : std::min<uint64_t>(nq, std::max(slots, slots_q))), plog_cap));
+                              (uint32_t)(idx->recompute ? nq : std::min<uint64_t>(nq, std::max(std::max(slots, slots_q), cg.tl_slots_q))),
+                              plog_cap));
   if (!idx->pool.slots || ((use_fast || (tl && idx->max_degree <= 128)) && !idx->d_ell && idx->d_off && idx->num_nodes)) {
     // not prepared (isl_index_prepare / isl_index_upload do this ahead of time)
     std::lock_guard<std::mutex> lock(idx->mu);
@@ -474,9 +492,12 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
   p.round_no = idx->round_no;
   if (resume) {
     p.qstate = ws.qstate;
-    p.qstate_words = isl_launch::fast_state_words(ef <= 64 ? 1 : ef <= 128 ? 2 : ef <= 256 ? 4 : 8, fg.hbits);
+    p.qstate_words = tl ? isl_launch::tl_state_words(ef, cg.tl_wcap, fg.hbits)
+                        : isl_launch::fast_state_words(ef <= 64 ? 1 : ef <= 128 ? 2 : ef <= 256 ? 4 : 8, fg.hbits);
     p.qflag = ws.qflag;
     p.qlist = ws.round_listed ? ws.qlist : nullptr;
+  } else if (tl && ws.retry_count) {
+    p.qlist = ws.qlist;  // the queries whose queue window was too small, alone, with a larger one
   }
   p.miss = ws.miss;
   p.miss_cap = (uint32_t)std::min<uint64_t>(ws.miss_cap, 0xFFFFFFFFull);
@@ -508,11 +529,32 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
   ws.ticket_clean = false;
   ISL_HIP(hipEventRecord(ws.ev0, st));
   if (tl) {
-    // build_distance_tables for the whole batch (pq.rs:307-338), then one wave per query
-    if (!warm) ISL_TRY(isl::pq_launch_tables(idx->pq, d_queries, nq, ws.tl_tables, st));
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(nq_grid, slots);
-    isl_launch::launch_two_level((int)idx->cfg.metric, p.emb_bf16 != 0, grid, cg.tl_lds, st, &p);
+    // build_distance_tables for the whole batch (pq.rs:307-338; once per call: the rounds of the
+    // recompute provider and a retry keep them), then one wave per query
+    if (!warm && !ws.tl_tables_built) {
+      ISL_TRY(isl::pq_launch_tables(idx->pq, d_queries, nq, ws.tl_tables, st));
+      ws.tl_tables_built = true;
+    }
+    const uint64_t n_run = resume ? ws.round_active : ws.retry_count ? ws.retry_count : nq_grid;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(n_run, slots);
+    const int metric = (int)idx->cfg.metric;
+    p.nq = warm ? 0u : (uint32_t)n_run;
+    if (tl_qh) {
+      p.qsel = ws.qsel;
+      p.qsel_h = ws.qsel_h;
+      isl_launch::launch_classify((uint32_t)std::min<uint64_t>(nq_grid, 2048), st, &p);
+      ISL_HIP(hipGetLastError());
+      isl_launch::launch_two_level(metric, true, false, true, (uint32_t)std::min<uint64_t>(nq_grid, cg.tl_slots_q),
+                                   cg.tl_lds_q, st, &p);
+      ISL_HIP(hipGetLastError());
+      p.qsel_mode = 1;  // the others
+      isl_launch::launch_two_level(metric, true, false, false, grid, cg.tl_lds, st, &p);
+      p.qsel_mode = 0;
+    } else {
+      isl_launch::launch_two_level(metric, p.emb_bf16 != 0, resume || (warm && idx->recompute), false, grid, cg.tl_lds, st, &p);
+    }
     ISL_HIP(hipGetLastError());
+    p.nq = warm ? 0u : (uint32_t)nq;
   } else
   if (use_fast && idx->is_hnsw && p.max_level > 0) {
     // HnswGraph::search: greedy descent through the upper layers first (its own kernel, so that
@@ -794,6 +836,39 @@ __global__ __launch_bounds__(64) void row_norm2_list_kernel(const float* __restr
   }
 }
 
+// query lists of a lane (rounds of the recompute provider, retries of the two-level search)
+isl_status ensure_qlist(isl::SearchWorkspace& ws, uint64_t nq) {
+  if (ws.qlist_cap >= nq && ws.qlist && ws.h_qlist && ws.qflag) return ISL_OK;
+  if (ws.qflag) (void)hipFree(ws.qflag);
+  if (ws.qlist) (void)hipFree(ws.qlist);
+  if (ws.h_qlist) (void)hipHostFree(ws.h_qlist);
+  ws.qflag = ws.qlist = ws.h_qlist = nullptr;
+  ws.qlist_cap = 0;
+  const uint64_t c = nq < 1024 ? 1024 : nq;
+  ISL_TRY(lane_malloc(ws, ws.qflag, c * 4));
+  ISL_TRY(lane_malloc(ws, ws.qlist, c * 4));
+  ISL_TRY(lane_host_malloc(ws, ws.h_qlist, c * 4));
+  ws.qlist_cap = c;
+  return ISL_OK;
+}
+
+// Two-level search: the queries of the finished launch whose approximate-queue window was too small
+// (QS_SCRATCH with payload 7) -> ws.h_qlist[0, *count).
+isl_status tl_collect_short(isl::SearchWorkspace& ws, uint64_t nq, uint32_t* count) {
+  *count = 0;
+  bool any = false;
+  for (uint64_t i = 0; i < nq && !any; ++i) any = ws.h_status[i] == QS_SCRATCH;
+  if (!any) return ISL_OK;
+  ISL_TRY(ensure_qlist(ws, nq));
+  std::vector<uint64_t> pay(nq);
+  ISL_HIP(hipMemcpy(pay.data(), ws.payload, nq * 8, hipMemcpyDeviceToHost));
+  uint32_t n = 0;
+  for (uint64_t i = 0; i < nq; ++i)
+    if (ws.h_status[i] == QS_SCRATCH && pay[i] == 7) ws.h_qlist[n++] = (uint32_t)i;
+  *count = n;
+  return ISL_OK;
+}
+
 isl_status prepare_recompute(isl::SearchWorkspace& ws, uint64_t nq, uint64_t state_words_per_query) {
   const uint64_t cap = std::min<uint64_t>(nq * 128 + 64, 0xFFFFFFF0ull);  // a hop keeps up to 128 rows
   if (ws.miss_cap < cap) {
@@ -808,18 +883,7 @@ isl_status prepare_recompute(isl::SearchWorkspace& ws, uint64_t nq, uint64_t sta
     ISL_TRY(lane_malloc(ws, ws.uniq_count, 4));
     ws.miss_cap = cap;
   }
-  if (ws.qlist_cap < nq) {
-    if (ws.qflag) (void)hipFree(ws.qflag);
-    if (ws.qlist) (void)hipFree(ws.qlist);
-    if (ws.h_qlist) (void)hipHostFree(ws.h_qlist);
-    ws.qflag = ws.qlist = ws.h_qlist = nullptr;
-    ws.qlist_cap = 0;
-    const uint64_t c = nq < 1024 ? 1024 : nq;
-    ISL_TRY(lane_malloc(ws, ws.qflag, c * 4));
-    ISL_TRY(lane_malloc(ws, ws.qlist, c * 4));
-    ISL_TRY(lane_host_malloc(ws, ws.h_qlist, c * 4));
-    ws.qlist_cap = c;
-  }
+  ISL_TRY(ensure_qlist(ws, nq));
   ISL_TRY(ensure(ws, ws.qstate, ws.qstate_words, std::max<uint64_t>(nq, 1) * state_words_per_query));
   return ISL_OK;
 }
@@ -834,16 +898,34 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
                        float* d_dist, uint32_t* d_count, hipStream_t user_stream, StreamMode mode,
                        const TwoLevelCall* tl = nullptr) {
   // two-level search: a query whose approximate queue outgrew the LDS window is never answered
-  // differently, the batch is run again with a window four times the size
+  // differently: the queries it happened to are run again, alone, with a window four times the size
   TwoLevelCall tcall;
   if (tl) { tcall = *tl; tl = &tcall; }
+  struct CallReset {  // the lane goes back with its per-call two-level fields cleared whatever happens below
+    isl::SearchWorkspace& w;
+    ~CallReset() { w.retry_count = 0; w.tl_tables_built = false; }
+  } call_reset{ws};
+  ws.retry_count = 0;
+  ws.tl_tables_built = false;
   if (!idx->recompute) {
+    double ms_total = 0.0;
     for (;;) {
       ISL_TRY(search_enqueue(idx, ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, user_stream, mode, tl));
-      bool window_short = false;
-      const isl_status st = search_finish(idx, ws, nullptr, tl ? &window_short : nullptr);
-      if (st == ISL_ERR_SEARCH && window_short && tcall.window_scale < 64) { tcall.window_scale *= 4; continue; }
-      return st;
+      ISL_TRY(search_finish(idx, ws, nullptr, nullptr, tl != nullptr));
+      if (!tl) return ISL_OK;  // (statuses evaluated by search_finish)
+      ms_total += ws.stats.kernel_ms;
+      uint32_t nshort = 0;
+      ISL_TRY(tl_collect_short(ws, nq, &nshort));
+      if (nshort && tcall.window_scale < 64) {
+        tcall.window_scale *= 4;
+        ws.retry_count = nshort;
+        hipStream_t st = mode == StreamMode::USER ? user_stream : ws.stream;
+        hipLaunchKernelGGL(copy_u32_kernel, dim3(16), dim3(256), 0, st, ws.h_qlist, ws.qlist, (uint64_t)nshort);
+        ISL_HIP(hipGetLastError());
+        continue;
+      }
+      ws.stats.kernel_ms = ms_total;
+      return search_statuses(ws, nq, nullptr);
     }
   }
   // the rounds rewrite the provider's row cache: one recompute search at a time
@@ -851,8 +933,11 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
   CallGeometry cg0;
   ISL_TRY(call_geometry(idx, d, k, ef, tl, cg0));
   const int S0 = cg0.ef <= 64 ? 1 : cg0.ef <= 128 ? 2 : cg0.ef <= 256 ? 4 : 8;
-  const bool resumable = cg0.use_fast && !tl;
-  ISL_TRY(prepare_recompute(ws, nq, resumable ? isl_launch::fast_state_words(S0, cg0.fg.hbits) : 1));
+  // searches that park and resume: the wave-per-query traversal and the two-level search (the
+  // heap-exact kernel alone -- ef > 512, rows past 128 ids -- re-runs a blocked query from its start)
+  const bool resumable = tl || cg0.use_fast;
+  ISL_TRY(prepare_recompute(ws, nq, tl ? isl_launch::tl_state_words(cg0.ef, cg0.tl_wcap, cg0.fg.hbits)
+                                       : resumable ? isl_launch::fast_state_words(S0, cg0.fg.hbits) : 1));
   ISL_TRY(ensure_lane_stream(ws));
   hipStream_t st = mode == StreamMode::USER ? user_stream : ws.stream;
   if (!idx->keep_rows) {  // every call starts from an empty cache: each node is encoded once per call
@@ -888,26 +973,40 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
   // through in, so a 256-row cache (one query at a time) is not cut short and a bug still ends.
   const uint64_t max_rounds = 64 + ((nq + max_active - 1) / max_active) * ((uint64_t)64 * cg0.ef + 4096);
   uint32_t stalled = 0;
+  std::vector<uint32_t> again;  // two-level search: queries to start over with a larger queue window
   for (;;) {
     ws.round_active = resumable ? active : 0u;
     ws.round_listed = listed;
     idx->round_no += 1;
     ISL_TRY(search_enqueue(idx, ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, user_stream, mode, tl));
     uint32_t misses = 0;
-    bool window_short = false;
-    const isl_status fst = search_finish(idx, ws, &misses, tl ? &window_short : nullptr, resumable);
-    if (fst == ISL_ERR_SEARCH && window_short && tcall.window_scale < 64) { tcall.window_scale *= 4; continue; }
-    ISL_TRY(fst);
+    ISL_TRY(search_finish(idx, ws, &misses, nullptr, resumable));
     kernel_ms += ws.stats.kernel_ms;
     rounds += 1;
     if (resumable) {  // next round: the queries that are waiting for rows, topped up with fresh ones
       uint32_t na = 0;
       for (uint64_t i = 0; i < next_fresh; ++i)
         if (ws.h_status[i] == QS_BLOCKED) ws.h_qlist[na++] = (uint32_t)i;
+      while (na < max_active && !again.empty()) { ws.h_qlist[na++] = again.back(); again.pop_back(); }
       while (na < max_active && next_fresh < nq) ws.h_qlist[na++] = next_fresh++;
+      if (!na && tl) {
+        // every query has run to its end; those whose queue window was too small start over -- alone,
+        // nothing is parked now -- with a window four times the size (and a state block to match)
+        uint32_t nshort = 0;
+        ISL_TRY(tl_collect_short(ws, nq, &nshort));
+        if (nshort && tcall.window_scale < 64) {
+          tcall.window_scale *= 4;
+          CallGeometry cg1;
+          ISL_TRY(call_geometry(idx, d, k, ef, tl, cg1));
+          ISL_TRY(ensure(ws, ws.qstate, ws.qstate_words,
+                         std::max<uint64_t>(nq, 1) * isl_launch::tl_state_words(cg1.ef, cg1.tl_wcap, cg1.fg.hbits)));
+          again.assign(ws.h_qlist, ws.h_qlist + nshort);
+          while (na < max_active && !again.empty()) { ws.h_qlist[na++] = again.back(); again.pop_back(); }
+        }
+      }
       active = na;
       listed = true;
-      if (!active) {  // every query has run to its end: now the statuses are final
+      if (!active) {  // now the statuses are final
         ISL_TRY(search_statuses(ws, nq, nullptr));
         break;
       }
@@ -1016,6 +1115,7 @@ isl::SearchWorkspace* claim_lane(const isl_index* idx) {
     if (!w.busy) {
       w.busy = true;
       w.waiting = false;
+      w.threaded = false;
       w.enqueued = false;
       w.token = 0;
       w.alloc_mark = w.alloc_events;
@@ -1069,9 +1169,45 @@ void host_copy_out(const isl::SearchWorkspace& ws, uint64_t nq, uint64_t k, uint
   memcpy(out_count, ws.h_count, nq * 4);
 }
 
+// Runs `body` (the synchronous form of a call, on the claimed lane `ws`) on a host thread; the
+// token's wait joins it.  The thread selects the index's device first (the HIP device is per thread).
+template <typename F>
+void start_worker(const isl_index* idx, isl::SearchWorkspace* ws, F body) {
+  ws->worker_status = ISL_OK;
+  ws->threaded = true;
+  ws->worker = new std::thread([idx, ws, body]() {
+    isl_status st = isl::use_device(idx->device);
+    if (st == ISL_OK) st = body();
+    ws->worker_status = st;
+    ws->worker_error = isl::last_error();
+  });
+}
+// true when the lane's call ran on a worker: *st = its status, the caller's error record = the worker's
+bool join_worker(isl::SearchWorkspace& ws, isl_status* st) {
+  if (!ws.threaded) return false;
+  if (ws.worker) {
+    ws.worker->join();
+    delete ws.worker;
+    ws.worker = nullptr;
+  }
+  ws.threaded = false;
+  *st = ws.worker_status;
+  if (*st != ISL_OK) isl::last_error() = ws.worker_error;
+  return true;
+}
+
 }  // namespace
 
 namespace isl {
+
+void join_lane_workers(const isl_index* idx) {
+  for (auto& w : idx->ws)
+    if (w.worker) {
+      w.worker->join();
+      delete w.worker;
+      w.worker = nullptr;
+    }
+}
 
 bool any_lane_busy(const isl_index* idx) {
   for (const auto& w : idx->ws)
@@ -1234,11 +1370,20 @@ isl_status isl_search_batch_device_async(const isl_index* idx, const float* d_qu
   if (!d_queries || !d_out_count || (k && (!d_out_ids || !d_out_dist)))
     return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
   ISL_TRY(isl::use_device(idx->device));
-  if (idx->recompute)
-    return isl::fail(ISL_ERR_UNSUPPORTED, "the recompute provider answers synchronously: use isl_search_batch_device");
   isl::SearchWorkspace* ws = claim_lane(idx);
   if (!ws) return no_lane();
   LaneGuard guard{idx, ws};
+  if (idx->recompute) {
+    // the provider works through the batch in rounds (search, encode what was missed, resume): the
+    // synchronous form on a thread of its own, ordered after the caller's stream
+    ISL_TRY(ensure_lane_stream(*ws));
+    ISL_HIP(hipEventRecord(ws->ev_in, (hipStream_t)stream));
+    ISL_HIP(hipStreamWaitEvent(ws->stream, ws->ev_in, 0));
+    start_worker(idx, ws, [=]() {
+      return search_sync(idx, *ws, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count, nullptr,
+                         StreamMode::OWN);
+    });
+  } else
   ISL_TRY(search_enqueue(idx, *ws, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count,
                          (hipStream_t)stream, StreamMode::OWN_AFTER_USER));
   {
@@ -1261,12 +1406,16 @@ isl_status isl_search_batch_async(const isl_index* idx, const float* queries, ui
   if (!queries || !out_count || (k && (!out_ids || !out_dist)))
     return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
   ISL_TRY(isl::use_device(idx->device));
-  if (idx->recompute)
-    return isl::fail(ISL_ERR_UNSUPPORTED, "the recompute provider answers synchronously: use isl_search_batch");
   isl::SearchWorkspace* ws = claim_lane(idx);
   if (!ws) return no_lane();
   LaneGuard guard{idx, ws};
   ISL_TRY(host_stage_in(*ws, queries, nq, d, k));
+  if (idx->recompute) {
+    start_worker(idx, ws, [=]() {
+      return search_sync(idx, *ws, ws->q_stage, nq, d, k, ef, ws->ids_stage, ws->dist_stage, ws->count_stage, nullptr,
+                         StreamMode::OWN);
+    });
+  } else
   ISL_TRY(search_enqueue(idx, *ws, ws->q_stage, nq, d, k, ef, ws->ids_stage, ws->dist_stage, ws->count_stage,
                          nullptr, StreamMode::OWN));
   ws->u_ids = out_ids;
@@ -1296,7 +1445,8 @@ isl_status isl_search_wait_stats(const isl_index* idx, uint64_t token, isl_searc
   }
   if (!ws) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "unknown or already completed search token");
   LaneGuard guard{idx, ws};
-  const isl_status st = search_finish(idx, *ws);  // the D2H result copies sit on the same stream
+  isl_status st = ISL_OK;
+  if (!join_worker(*ws, &st)) st = search_finish(idx, *ws);  // the D2H result copies sit on the same stream
   if (st == ISL_OK && ws->u_count) host_copy_out(*ws, ws->nq_inflight, ws->k_inflight, ws->u_ids, ws->u_dist, ws->u_count);
   if (stats) *stats = ws->stats;
   note_last_stats(idx, ws->stats);
@@ -1309,13 +1459,34 @@ isl_status isl_search_stream_wait(const isl_index* idx, uint64_t token, void* st
   if (!idx) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "index is NULL");
   if (token == 0) return ISL_OK;
   ISL_TRY(isl::use_device(idx->device));
-  std::lock_guard<std::mutex> lock(idx->mu);
-  for (auto& w : idx->ws)
-    if (w.busy && w.token == token) {
-      ISL_HIP(hipStreamWaitEvent((hipStream_t)stream, w.ev1, 0));  // recorded behind the last search kernel
-      return ISL_OK;
-    }
-  return isl::fail(ISL_ERR_INVALID_ARGUMENT, "unknown or already completed search token");
+  isl::SearchWorkspace* found = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    for (auto& w : idx->ws)
+      if (w.busy && w.token == token) {
+        if (!w.threaded) {
+          ISL_HIP(hipStreamWaitEvent((hipStream_t)stream, w.ev1, 0));  // recorded behind the last search kernel
+          return ISL_OK;
+        }
+        if (!w.worker) return ISL_OK;  // already joined
+        if (w.waiting) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "the call is being waited for on another thread");
+        found = &w;
+        w.waiting = true;  // (keeps isl_search_wait of another thread off the lane while we join)
+        break;
+      }
+  }
+  if (!found) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "unknown or already completed search token");
+  // a call that runs on a worker thread (recompute provider, two-level search): its kernels are
+  // enqueued round by round, so the host waits for the worker here; the call's status stays with the
+  // lane for isl_search_wait
+  found->worker->join();
+  delete found->worker;
+  found->worker = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    found->waiting = false;
+  }
+  return ISL_OK;
 }
 
 // host-pointer entry: stage the queries, search on the lane's stream, copy the answers back
@@ -1413,6 +1584,39 @@ isl_status isl_search_two_level_batch_device(const isl_index* idx, const float* 
                                     (hipStream_t)stream, StreamMode::USER, &tl);
   note_last_stats(idx, ws->stats);
   return st;
+}
+
+isl_status isl_search_two_level_batch_device_async(const isl_index* idx, const float* d_queries, uint64_t nq,
+                                                   uint64_t d, uint64_t k, uint64_t ef, float rerank_ratio,
+                                                   uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count,
+                                                   void* stream, uint64_t* token) {
+  if (!token) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "token is NULL");
+  *token = 0;
+  int done = 0;
+  ISL_TRY(precheck(idx, nq, d, k, d_out_count, true, &done));
+  if (done == 1) return ISL_OK;
+  ISL_TRY(precheck_two_level(idx, d));
+  if (!d_queries || !d_out_count || (k && (!d_out_ids || !d_out_dist)))
+    return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
+  ISL_TRY(isl::use_device(idx->device));
+  isl::SearchWorkspace* ws = claim_lane(idx);
+  if (!ws) return no_lane();
+  LaneGuard guard{idx, ws};
+  ISL_TRY(ensure_lane_stream(*ws));
+  ISL_HIP(hipEventRecord(ws->ev_in, (hipStream_t)stream));
+  ISL_HIP(hipStreamWaitEvent(ws->stream, ws->ev_in, 0));
+  const TwoLevelCall tl{rerank_ratio};
+  start_worker(idx, ws, [=]() {
+    return search_sync(idx, *ws, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count, nullptr, StreamMode::OWN,
+                       &tl);
+  });
+  {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    ws->token = idx->next_token++;
+    *token = ws->token;
+  }
+  guard.keep();
+  return ISL_OK;
 }
 
 isl_status isl_search(const isl_index* idx, const float* query, uint64_t d, uint64_t k,

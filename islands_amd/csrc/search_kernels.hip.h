@@ -1331,6 +1331,8 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
 //   * only the smallest tl_wcap entries of AQ are kept: an entry that drops out is larger than
 //     tl_wcap others for good, so it can only matter when ceil(a * |AQ|) outgrows the window --
 //     then the query fails (QS_SCRATCH), it is never answered differently.
+constexpr uint32_t kTlPairs = 16;                         // (neighbour, subquantizer) pairs per lane and chunk
+constexpr uint32_t kTlLdsWords = kTlPairs * 64 + 64 + 4;   // their table entries in LDS (+ one pad word per row)
 __device__ __forceinline__ uint64_t rl_u64(uint64_t v, int lane) {
   return ((uint64_t)rl_u((uint32_t)(v >> 32), lane) << 32) | (uint64_t)rl_u((uint32_t)v, lane);
 }
@@ -1375,8 +1377,22 @@ __device__ uint32_t tl_merge(uint64_t* arr, uint32_t len, uint64_t nk, uint32_t 
   return len + cnt;
 }
 
-template <int METRIC_API, typename ROWT>
+// RESUME = searches over the recompute provider: a query whose promoted rows are not in the row
+// cache reports them and parks -- R, the queue window, the visited table and its counters go to its
+// state block -- and is taken up again in the promotion it stopped at once the provider has encoded
+// them.  (Promotions are flagged in the window only when their rows were there, so the parked
+// promotion is found again by the same scan; everything before it in the hop is complete.)
+// QH = bf16 rows and a query whose elements are all bf16 values: the query stays bf16 in LDS
+// (half the LDS of a long query), like leann_search_fast's instantiation of that name.
+// words of one parked query: 16 scalars, R, the window, the visited table
+__host__ __device__ inline uint32_t tl_res_entries(uint32_t ef) { return (ef + 63u) / 64u * 64u + 64u; }
+__host__ __device__ inline uint32_t tl_state_words_of(uint32_t ef, uint32_t wcap, uint32_t hbits) {
+  return 16u + 2u * tl_res_entries(ef) + 2u * (wcap + 64u) + (1u << hbits);
+}
+
+template <int METRIC_API, typename ROWT, bool RESUME = false, bool QH = false>
 __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
+  static_assert(!QH || (sizeof(ROWT) == 2 && !RESUME), "the bf16 query operand goes with bf16 rows");
   constexpr int METRIC = METRIC_API == ISL_METRIC_COSINE ? METRIC_COSINE_PRE : METRIC_API;
   const ROWT* const emb = reinterpret_cast<const ROWT*>(p.emb);
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1386,12 +1402,14 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
   const uint32_t hlimit = hcap - hcap / 8;
   const uint32_t ef = p.ef;
   const uint32_t wcap = p.tl_wcap;
+  const uint32_t resn = tl_res_entries(ef);
   uint32_t* htab = reinterpret_cast<uint32_t*>(smem);
   uint64_t* win = reinterpret_cast<uint64_t*>(htab + hcap);  // hcap * 4 is a multiple of 8
   uint64_t* res = win + (wcap + 64);
-  uint64_t* nbuf = res + ((ef + 63) / 64 * 64 + 64);
-  uint32_t* scratch = reinterpret_cast<uint32_t*>(nbuf + 64);
-  float* qs = reinterpret_cast<float*>(scratch + 64);
+  uint64_t* nbuf = res + resn;
+  uint32_t* scratch = reinterpret_cast<uint32_t*>(nbuf + 64);  // 64 ids + 64 window positions
+  float* tlv = reinterpret_cast<float*>(scratch + 128);  // table entries of one chunk of pairs, rows of m + 1
+  float* qs = tlv + kTlLdsWords;
   const uint32_t ocap = 1u << p.obits;
   const uint32_t omask = ocap - 1;
   const uint32_t olimit = ocap - ocap / 4;
@@ -1400,12 +1418,47 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
 
   for (;;) {
     uint32_t qi = 0;
-    if (lane == 0) qi = atomicAdd(&p.ticket[0], 1u);
-    qi = uni(qi);
-    if (qi >= p.nq) break;
+    if constexpr (QH) {
+      if (lane == 0) qi = atomicAdd(&p.ticket[4], 1u);
+      qi = uni(qi);
+      if (qi >= *((volatile uint32_t*)&p.ticket[7])) break;
+      qi = p.qsel_h[qi];
+    } else {
+      bool listed = false;
+      if constexpr (sizeof(ROWT) == 2 && !RESUME) listed = p.qsel_mode != 0u;
+      if (listed) {  // the queries the bf16-query launch passed on
+        if (lane == 0) qi = atomicAdd(&p.ticket[6], 1u);
+        qi = uni(qi);
+        if (qi >= *((volatile uint32_t*)&p.ticket[5])) break;
+        qi = p.qsel[qi];
+      } else {
+        if (lane == 0) qi = atomicAdd(&p.ticket[0], 1u);
+        qi = uni(qi);
+        if (qi >= p.nq) break;
+        if (p.qlist) qi = p.qlist[qi];  // a round of the recompute provider / the queries of a retry
+      }
+    }
+    uint32_t* qst = nullptr;
+    bool resumed = false;
+    if constexpr (RESUME) {
+      qst = p.qstate + (size_t)qi * p.qstate_words;
+      resumed = uni(p.qflag[qi]) == 1u;
+      otab = p.otab + (size_t)qi * ocap;  // a parked query may come back on another wave
+    }
 
-    for (uint32_t i = lane; i < hcap; i += 64) htab[i] = EMPTY;
-    const float q_norm = load_query<METRIC>(p.queries + (uint64_t)qi * p.d, p.d, qs);  // syncs
+    if (resumed) { for (uint32_t i = lane; i < hcap; i += 64) htab[i] = qst[16 + 2 * resn + 2 * (wcap + 64) + i]; }
+    else { for (uint32_t i = lane; i < hcap; i += 64) htab[i] = EMPTY; }
+    float q_norm;
+    if constexpr (QH) {
+      bool representable;
+      q_norm = load_query_bf16<METRIC>(p.queries + (uint64_t)qi * p.d, p.d, qs, &representable);  // syncs
+      if (!representable) {  // (cannot happen after classify_queries_kernel; kept as a guard)
+        if (lane == 0) p.qsel[atomicAdd(&p.ticket[5], 1u)] = qi;
+        continue;
+      }
+    } else {
+      q_norm = load_query<METRIC>(p.queries + (uint64_t)qi * p.d, p.d, qs);  // syncs
+    }
     const float* tables = p.tl_tables + (uint64_t)qi * m * K;
 
     uint32_t rlen = 0, wlen = 0, aq_total = 0;
@@ -1414,17 +1467,29 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
     uint32_t status = QS_OK;
     uint64_t payload = 0;
     uint32_t cH = 0, cE = 0, cV = 0, cP = 0;
+    bool parked = false;
+    bool in_promotion = false;  // RESUME: the parked hop's promotions come before anything is popped
 
+    if (resumed) {
+      rlen = qst[0]; wlen = qst[1]; aq_total = qst[2]; hcount = qst[3]; ocount = qst[4]; ovf = qst[5] != 0u;
+      cH = qst[6]; cE = qst[7]; cV = qst[8]; cP = qst[9];
+      const uint64_t* sres = reinterpret_cast<const uint64_t*>(qst + 16);
+      const uint64_t* swin = sres + resn;
+      for (uint32_t i = lane; i < rlen; i += 64) res[i] = sres[i];
+      for (uint32_t i = lane; i < wlen; i += 64) win[i] = swin[i];
+      in_promotion = true;
+      wave_sync();
+    } else
     if ((uint64_t)p.entry >= p.nvec) {  // provider.compute_embedding(entry), leann.rs:911
       status = QS_NODE_NOT_FOUND;
       payload = p.entry;
     } else if (!rows_present(p, p.entry, 1)) {
-      status = QS_BLOCKED;
+      status = QS_BLOCKED;  // nothing to park: the query starts over once the entry's row is there
     } else {
       const uint32_t entry = p.entry;
       const uint32_t erow = row_index(p, entry, true);
       const float e_aux = METRIC == METRIC_COSINE_PRE ? p.norm2[erow] : 0.0f;
-      float ed = direct_distances<METRIC, ROWT>(emb, p.stride, p.d, erow, 1, qs, q_norm, e_aux);
+      float ed = direct_distances<METRIC, ROWT, QH>(emb, p.stride, p.d, erow, 1, qs, q_norm, e_aux);
       ed = rl_f(ed, 0);
       cV = 1;
       if (lane == 0) {
@@ -1437,6 +1502,7 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
     }
 
     while (status == QS_OK) {
+     if (!in_promotion) {
       // extract_min(EQ): the first unexpanded member of R; none left -> done (lines 5-9)
       uint32_t e = 0xFFFFFFFFu;
       for (uint32_t c = 0; c < rlen; c += 64) {
@@ -1465,35 +1531,7 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
         const uint32_t nid = active ? p.adj[o0 + base + lane] : EMPTY;
         const uint32_t batch = deg - base < 64 ? deg - base : 64;
         if (!ovf && hcount + batch > hlimit) ovf = true;
-        bool is_new = false;
-        if (active) {
-          uint32_t h = hslot(nid, p.hbits);
-          if (!ovf) {
-            for (;;) {
-              uint32_t old = atomicCAS(&htab[h], EMPTY, nid);
-              if (old == EMPTY) { is_new = true; break; }
-              if (old == nid) break;
-              h = (h + 1) & hmask;
-            }
-          } else {
-            bool found = false;
-            for (;;) {
-              uint32_t cur = htab[h];
-              if (cur == nid) { found = true; break; }
-              if (cur == EMPTY) break;
-              h = (h + 1) & hmask;
-            }
-            if (!found) {
-              uint32_t g = hslot(nid, p.obits);
-              for (;;) {
-                uint32_t old = atomicCAS(&otab[g], EMPTY, nid);
-                if (old == EMPTY) { is_new = true; break; }
-                if (old == nid) break;
-                g = (g + 1) & omask;
-              }
-            }
-          }
-        }
+        const bool is_new = visited_insert(htab, p.hbits, hmask, ovf, otab, p.obits, omask, nid, active);
         const uint64_t nm = ballot(is_new);
         const uint32_t nu = (uint32_t)__popcll(nm);
         if (!ovf) hcount += nu;
@@ -1513,25 +1551,62 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
           payload = rl_u(uid, __ffsll((long long)bad) - 1);
           break;
         }
-        // table_distance, pq.rs:341-348: left fold over the subquantizers.  Eight codes per 16-byte
-        // load, their eight table entries fetched together, then added in order.
+        // table_distance, pq.rs:341-348: s = sum over the subquantizers j of tables[j][code_j], a left
+        // fold in j.  The nu * m (neighbour, subquantizer) pairs are spread over the lanes -- lane order
+        // = j fastest, so a neighbour's codes are one contiguous run -- and fetched kTlPairs per lane at a
+        // time: all code loads of a chunk are in flight together, then all table reads (two dependent
+        // round trips per chunk of up to 1024 pairs, where one lane per neighbour made 2 * m / 8 of
+        // them).  The entries go through LDS (rows padded by one word: lanes that fold different
+        // neighbours hit different banks) and lane n folds neighbour n's entries in subquantizer
+        // order: the same additions in the same order.
         float s = 0.0f;
-        if (lane < nu) {
-          const uint16_t* cr = p.tl_codes + (uint64_t)uid * m;
-          if ((m & 7u) == 0) {
-            const uint4* cv = reinterpret_cast<const uint4*>(cr);
-#pragma unroll 2
-            for (uint32_t j0 = 0; j0 < m; j0 += 8) {
-              const uint4 c8 = cv[j0 >> 3];
-              const float* tb = tables + (uint64_t)j0 * K;
-              const float t0 = tb[c8.x & 0xFFFFu], t1 = tb[K + (c8.x >> 16)];
-              const float t2 = tb[2 * K + (c8.y & 0xFFFFu)], t3 = tb[3 * K + (c8.y >> 16)];
-              const float t4 = tb[4 * K + (c8.z & 0xFFFFu)], t5 = tb[5 * K + (c8.z >> 16)];
-              const float t6 = tb[6 * K + (c8.w & 0xFFFFu)], t7 = tb[7 * K + (c8.w >> 16)];
-              s += t0; s += t1; s += t2; s += t3; s += t4; s += t5; s += t6; s += t7;
+        {
+          const uint32_t per_chunk = m <= kTlPairs * 64u ? (kTlPairs * 64u) / m : 0u;  // neighbours per chunk
+          if (per_chunk == 0) {  // a row of codes longer than a chunk (m > 1024): one lane per neighbour
+            if (lane < nu) {
+              const uint16_t* cr = p.tl_codes + (uint64_t)uid * m;
+              for (uint32_t j = 0; j < m; ++j) s += tables[(uint64_t)j * K + cr[j]];
             }
           } else {
-            for (uint32_t j = 0; j < m; ++j) s += tables[(uint64_t)j * K + cr[j]];
+            for (uint32_t n0 = 0; n0 < nu; n0 += per_chunk) {
+              const uint32_t cnt = nu - n0 < per_chunk ? nu - n0 : per_chunk;
+              const uint32_t total = cnt * m;
+              uint32_t cn[kTlPairs], cj[kTlPairs];
+              uint32_t code[kTlPairs];
+              // pair t = lane + 64 * i  ->  neighbour t / m, subquantizer t % m, kept incrementally
+              uint32_t n = lane / m, j = lane - n * m;
+#pragma unroll
+              for (uint32_t i = 0; i < kTlPairs; ++i) {
+                cn[i] = n;
+                cj[i] = j;
+                j += 64u;
+                while (j >= m) { j -= m; n += 1u; }
+              }
+#pragma unroll
+              for (uint32_t i = 0; i < kTlPairs; ++i) {
+                const uint32_t t = lane + 64u * i;
+                code[i] = 0u;
+                if (t < total) code[i] = p.tl_codes[(uint64_t)scratch[n0 + cn[i]] * m + cj[i]];
+              }
+              float tv[kTlPairs];
+#pragma unroll
+              for (uint32_t i = 0; i < kTlPairs; ++i) {
+                const uint32_t t = lane + 64u * i;
+                tv[i] = 0.0f;
+                if (t < total) tv[i] = tables[(uint64_t)cj[i] * K + code[i]];
+              }
+#pragma unroll
+              for (uint32_t i = 0; i < kTlPairs; ++i) {
+                const uint32_t t = lane + 64u * i;
+                if (t < total) tlv[cn[i] * (m + 1u) + cj[i]] = tv[i];
+              }
+              wave_sync();
+              if (lane >= n0 && lane < n0 + cnt) {
+                const float* row = tlv + (lane - n0) * (m + 1u);
+                for (uint32_t jj = 0; jj < m; ++jj) s += row[jj];
+              }
+              wave_sync();
+            }
           }
         }
         const float ad = sqrtf(s);
@@ -1542,54 +1617,74 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
         if (wlen > wcap) wlen = wcap;
       }
       if (status != QS_OK || aq_total == 0) continue;
+     }
+     in_promotion = false;
 
       // Phase 2 (lines 19-27): M = the first ceil(a * |AQ|) entries of AQ, at least one
       const float tf = ceilf(p.tl_ratio * (float)aq_total);
       uint32_t ntop = tf >= 1.0f ? (tf >= (float)aq_total ? aq_total : (uint32_t)tf) : 1u;
       if (ntop > aq_total) ntop = aq_total;
       if (ntop > wlen) { status = QS_SCRATCH; payload = 7; break; }
-      // the unpromoted members of M are collected over the whole prefix (up to 64 at a time), so
-      // that their rows are fetched in one distance pass and merged into R at once
-      auto promote = [&](uint32_t pc) {
+      // The unpromoted members of M are collected over the prefix in groups of up to 64 (a chunk of
+      // 64 window positions never straddles two groups), so that a group's rows are fetched in one
+      // distance pass and merged into R at once.  A group is flagged "promoted" only once its rows
+      // were there: a parked promotion is found again by the same scan.
+      uint32_t c = 0;
+      while (c < ntop && status == QS_OK) {
+        uint32_t pend = 0;
+        for (; c < ntop; c += 64) {
+          const uint32_t i = c + lane;
+          const uint64_t x = i < ntop ? win[i] : ~0ull;
+          const bool un = i < ntop && !(x & 1ull);
+          const uint64_t um = ballot(un);
+          const uint32_t pc = (uint32_t)__popcll(um);
+          if (!pc) continue;
+          if (pend + pc > 64) break;  // this chunk opens the next group
+          const uint32_t rank = (uint32_t)__popcll(um & ((1ull << lane) - 1ull));
+          if (un) {
+            scratch[pend + rank] = (uint32_t)(x >> 1) & ID_MASK;
+            scratch[64 + pend + rank] = i;
+          }
+          pend += pc;
+        }
+        if (!pend) break;
+        const uint32_t pc = pend;
         wave_sync();
         const uint32_t pid = lane < pc ? scratch[lane] : 0u;
+        const uint32_t ppos = lane < pc ? scratch[64 + lane] : 0u;
         wave_sync();
         const uint64_t bad = ballot(lane < pc && (uint64_t)pid >= p.nvec);
         if (bad) {
           status = QS_NODE_NOT_FOUND;
           payload = rl_u(pid, __ffsll((long long)bad) - 1);
-          return;
+          break;
         }
-        if (!rows_present(p, pid, pc)) { status = QS_BLOCKED; return; }
+        if (!rows_present(p, pid, pc)) {
+          status = QS_BLOCKED;
+          if constexpr (RESUME) {  // park: everything the rest of the search depends on
+            if (lane == 0) {
+              qst[0] = rlen; qst[1] = wlen; qst[2] = aq_total; qst[3] = hcount; qst[4] = ocount; qst[5] = ovf ? 1u : 0u;
+              qst[6] = cH; qst[7] = cE; qst[8] = cV; qst[9] = cP;
+              p.qflag[qi] = 1u;
+            }
+            uint64_t* sres = reinterpret_cast<uint64_t*>(qst + 16);
+            uint64_t* swin = sres + resn;
+            for (uint32_t i = lane; i < rlen; i += 64) sres[i] = res[i];
+            for (uint32_t i = lane; i < wlen; i += 64) swin[i] = win[i];
+            for (uint32_t i = lane; i < hcap; i += 64) qst[16 + 2 * resn + 2 * (wcap + 64) + i] = htab[i];
+            parked = true;
+          }
+          break;
+        }
+        if (lane < pc) win[ppos] |= 1ull;
         cV += pc;
         const uint32_t prow = row_index(p, pid, lane < pc);
         const float r_aux = (METRIC == METRIC_COSINE_PRE && lane < pc) ? p.norm2[prow] : 0.0f;
-        const float nd = direct_distances<METRIC, ROWT>(emb, p.stride, p.d, prow, pc, qs, q_norm, r_aux);
+        const float nd = direct_distances<METRIC, ROWT, QH>(emb, p.stride, p.d, prow, pc, qs, q_norm, r_aux);
         const uint64_t rkey = ((uint64_t)ordkey(nd) << 32) | ((uint64_t)pid << 1);
         rlen = tl_merge(res, rlen, rkey, pc, nbuf);
         if (rlen > ef) rlen = ef;  // lines 26-27
-      };
-      uint32_t pend = 0;
-      for (uint32_t c = 0; c < ntop && status == QS_OK; c += 64) {
-        const uint32_t i = c + lane;
-        const uint64_t x = i < ntop ? win[i] : ~0ull;
-        const bool un = i < ntop && !(x & 1ull);
-        const uint64_t um = ballot(un);
-        const uint32_t pc = (uint32_t)__popcll(um);
-        if (!pc) continue;
-        if (pend + pc > 64) {
-          promote(pend);
-          pend = 0;
-          if (status != QS_OK) break;
-        }
-        const uint32_t rank = (uint32_t)__popcll(um & ((1ull << lane) - 1ull));
-        if (un) {
-          win[i] = x | 1ull;
-          scratch[pend + rank] = (uint32_t)(x >> 1) & ID_MASK;
-        }
-        pend += pc;
       }
-      if (pend && status == QS_OK) promote(pend);
     }
 
     const uint32_t outn = rlen < p.k ? rlen : p.k;
@@ -1608,8 +1703,11 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
       p.ctr[qi * 4 + 1] = cE;
       p.ctr[qi * 4 + 2] = cV;
       p.ctr[qi * 4 + 3] = cP;
+      if constexpr (RESUME) {
+        if (!parked) p.qflag[qi] = 0u;  // finished, failed, or blocked on its entry point: a fresh start next time
+      }
     }
-    if (ovf) {
+    if (ovf && !parked) {
       for (uint32_t i = lane; i < ocap; i += 64) otab[i] = EMPTY;
     }
     wave_sync();
@@ -1650,7 +1748,9 @@ void launch_fast_s8(int metric, bool wide, bool bf16, bool resume, bool qh, uint
 // words of one parked query (RESUME) for result sets of S x 64 entries and a visited table of 1 << hbits
 inline uint32_t fast_state_words(int S, uint32_t hbits) { return 208u + (uint32_t)S * 128u + (1u << hbits); }
 void launch_exact(int metric, bool hnsw, uint32_t grid, size_t lds, hipStream_t st, const void* params);
-void launch_two_level(int metric, bool bf16, uint32_t grid, size_t lds, hipStream_t st, const void* params);
+// resume = the RESUME instantiation (recompute provider, f32 rows); qh = bf16 rows, query held as bf16 in LDS
+void launch_two_level(int metric, bool bf16, bool resume, bool qh, uint32_t grid, size_t lds, hipStream_t st, const void* params);
+inline uint32_t tl_state_words(uint32_t ef, uint32_t wcap, uint32_t hbits) { return tl_state_words_of(ef, wcap, hbits); }
 void launch_descent(int metric, uint32_t grid, size_t lds, hipStream_t st, const void* params);
 void launch_classify(uint32_t grid, hipStream_t st, const void* params);
 }  // namespace isl_launch

@@ -239,3 +239,139 @@ def test_two_level_many_queries_and_large_ef(orc):
     assert_same(orc, idx, csr, v, cb, codes, q[:12], 20, 600, 0.2)
     assert_same(orc, idx, csr, v, cb, codes, q[:12], 700, 16, 0.5)     # ef = max(ef, k)
     del pq
+
+
+def test_two_level_bf16_rows_bf16_valued_and_mixed_queries(orc):
+    """bf16 rows: queries whose elements are all bf16 values are answered by the instantiation that
+    keeps the query as bf16 in LDS, the others by the float32-query one -- in one call, with the same
+    answers as the oracle either way (d large enough for the two to share a visited-table size)."""
+    n, d, m, K = 1500, 1024, 16, 64
+    v = clustered_vectors(n, d, 53, per_cluster=50)
+    vb = (v.view(np.uint32) >> 16).astype(np.uint16)
+    vw = (vb.astype(np.uint32) << 16).view(np.float32)
+    off, nb = knn_graph(vw, 16, seed=5)
+    cb, codes = make_pq(vw, m, K, 9)
+    csr = orc.Csr(off, nb, entry_point=0)
+    g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels,
+                    entry_point=0, num_nodes=n, degree_counts=csr.degree_counts)
+    idx = ia.LeannIndex.from_csr(g, None, dimension=d).upload(0)
+    idx.set_embeddings_bf16(vb)
+    pq = attach_pq(idx, cb, codes)
+    q = clustered_vectors(12, d, 54, per_cluster=50)
+    qb = ((q.view(np.uint32) >> 16) << 16).view(np.float32).copy()   # bf16-valued
+    mixed = qb.copy()
+    mixed[::3] = q[::3]                                              # every third query is not
+    for qq in (qb, mixed, q):
+        assert_same(orc, idx, csr, vw, cb, codes, qq, 10, 64, 0.3)
+    del pq
+
+
+def _recompute_pair(orc, cache_rows=None, n=1600, deg=20):
+    from test_gpu_encoder import _recompute_case
+    cfg, enc, tok, lens, emb = _recompute_case(orc, n=n, seed=11, min_len=9)
+    d = emb.shape[1]
+    off, nb = random_csr(n, deg, 3)
+    csr = orc.Csr(off, nb, entry_point=5)
+    cb, codes = make_pq(emb, 8, 64, 12)
+    g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels, entry_point=5,
+                    num_nodes=n, degree_counts=csr.degree_counts)
+    mem_idx = ia.LeannIndex.from_csr(g, None, dimension=d).upload(0)
+    mem_idx.set_embeddings(emb)
+    pq = attach_pq(mem_idx, cb, codes)
+    rec_idx = ia.LeannIndex.from_csr(g, None, dimension=d).upload(0)
+    rec_idx.set_recompute_provider(enc, tok, lens, cache_rows=cache_rows)
+    rec_idx.set_pq_codes(pq, codes)
+    return emb, csr, cb, codes, mem_idx, rec_idx, pq, enc
+
+
+def test_two_level_recompute_parks_and_resumes_with_a_small_row_cache(orc):
+    """The two-level search over the recompute provider parks a query at the promotion whose rows
+    are not in the row cache and resumes it there (round 2 re-ran it from its start and needed its
+    whole traversal resident): a cache of 512 rows for 1600 nodes turns over inside the call, and
+    ids, distance bits and counters still equal the in-memory provider's.  ratio 1 with a small ef
+    also takes the window retry (alone, state block resized) over the recompute rounds."""
+    emb, csr, cb, codes, mem_idx, rec_idx, pq, enc = _recompute_pair(orc, cache_rows=512)
+    q = emb[::53] + np.float32(0.02)
+    for (k, ef, ratio) in ((10, 64, 0.4), (10, 200, 0.3), (3, 6, 1.0)):
+        want = mem_idx.search_two_level_batch(q, k, ef, ratio)
+        want_stats = mem_idx.last_stats()
+        got = rec_idx.search_two_level_batch(q, k, ef, ratio)
+        st = rec_idx.last_stats()
+        assert got[2].tolist() == want[2].tolist() and got[0].tolist() == want[0].tolist(), (k, ef, ratio)
+        assert got[1].view(np.uint32).tolist() == want[1].view(np.uint32).tolist()
+        for f in ("expansions", "edges", "evals", "pushes"):
+            assert st[f] == want_stats[f], (f, k, ef, ratio)
+        assert st["recompute_rounds"] > 2 and st["encoded_nodes"] > 0
+    # the slab turned over: more rows were encoded than it holds
+    got = rec_idx.search_two_level_batch(q, 10, 200, 0.6)
+    assert rec_idx.last_stats()["encoded_nodes"] >= 512
+    for i in range(0, q.shape[0], 7):
+        r = orc.two_level_search(csr, emb, cb, codes, q[i], 10, 200, 0.6)
+        c = int(got[2][i])
+        assert got[0][i, :c].tolist() == r.ids.tolist()
+    del pq
+
+
+def test_two_level_async_calls_overlap_and_retry(orc):
+    """isl_search_two_level_batch_device_async: several calls in flight on the index's lanes, each
+    completed by its token with its own counters; one of them needs the window retry."""
+    import torch
+    n, d, m, K = 3000, 32, 8, 32
+    v = clustered_vectors(n, d, 71)
+    off, nb = random_csr(n, 64, 12)
+    cb, codes = make_pq(v, m, K, 13)
+    csr = orc.Csr(off, nb, entry_point=1)
+    idx = make_index(csr, v)
+    pq = attach_pq(idx, cb, codes)
+    calls = [(clustered_vectors(40, d, 100 + i), kk, ef, a) for i, (kk, ef, a) in
+             enumerate([(5, 64, 0.3), (3, 6, 1.0), (10, 128, 0.5), (5, 64, 0.3), (10, 32, 0.2)])]
+    outs, toks = [], []
+    for (q, kk, ef, a) in calls:
+        dq = torch.from_numpy(q).cuda()
+        o = (torch.zeros((q.shape[0], kk), dtype=torch.int64, device="cuda"),
+             torch.zeros((q.shape[0], kk), dtype=torch.float32, device="cuda"),
+             torch.zeros(q.shape[0], dtype=torch.int32, device="cuda"))
+        outs.append((dq, o))
+        toks.append(idx.search_two_level_batch_device_async(dq.data_ptr(), q.shape[0], d, kk, ef, a, o[0].data_ptr(),
+                                                           o[1].data_ptr(), o[2].data_ptr()))
+    for (q, kk, ef, a), (dq, o), t in zip(calls, outs, toks):
+        st = idx.wait_stats(t)
+        assert st["queries"] == q.shape[0]
+        ids, dist, cnt = o[0].cpu().numpy(), o[1].cpu().numpy(), o[2].cpu().numpy()
+        ev = 0
+        for i in range(q.shape[0]):
+            r = orc.two_level_search(csr, v, cb, codes, q[i], kk, ef, a)
+            c = int(cnt[i])
+            assert ids[i, :c].tolist() == r.ids.tolist(), (kk, ef, a, i)
+            assert bits(dist[i, :c]).tolist() == bits(r.dist).tolist()
+            ev += r.counters["evals"]
+        assert st["evals"] == ev
+    with pytest.raises(ia.CoreError):
+        idx.wait(toks[0])
+    del pq
+
+
+def test_recompute_index_on_the_async_entry_points(orc):
+    """isl_search_batch_async / isl_search_batch_device_async accept an index with the recompute
+    provider (round 2 refused them): the rounds run on a host thread of the library's, the token's
+    wait hands over status, answers and counters -- those of the synchronous call."""
+    import torch
+    emb, csr, cb, codes, mem_idx, rec_idx, pq, enc = _recompute_pair(orc)
+    q1, q2 = emb[::53] + np.float32(0.02), emb[5::71] + np.float32(0.01)
+    want1, want2 = mem_idx.search_batch(q1, 10, 64), mem_idx.search_batch(q2, 5, 32)
+    t1 = rec_idx.search_batch_async(q1, 10, 64)
+    t2 = rec_idx.search_batch_async(q2, 5, 32)          # second call: queued behind the first one's rounds
+    g2, g1 = rec_idx.wait(t2), rec_idx.wait(t1)
+    for got, want in ((g1, want1), (g2, want2)):
+        assert got[2].tolist() == want[2].tolist() and got[0].tolist() == want[0].tolist()
+        assert got[1].view(np.uint32).tolist() == want[1].view(np.uint32).tolist()
+    dq = torch.from_numpy(q1).cuda()
+    o = (torch.zeros((q1.shape[0], 10), dtype=torch.int64, device="cuda"),
+         torch.zeros((q1.shape[0], 10), dtype=torch.float32, device="cuda"),
+         torch.zeros(q1.shape[0], dtype=torch.int32, device="cuda"))
+    t = rec_idx.search_batch_device_async(dq.data_ptr(), q1.shape[0], emb.shape[1], 10, 64, o[0].data_ptr(),
+                                          o[1].data_ptr(), o[2].data_ptr())
+    st = rec_idx.wait_stats(t)
+    assert st["recompute_rounds"] > 2 and st["encoded_nodes"] > 0
+    assert o[0].cpu().numpy().astype(np.uint64).tolist() == want1[0].tolist()
+    del pq
