@@ -204,12 +204,15 @@ typedef struct isl_search_stats {
 } isl_search_stats;
 
 /* Sets up everything a search needs so that no later call allocates, creates a stream or
- * synchronises for set-up: `lanes` (1..16) search lanes sized for batches of up to max_nq queries
+ * synchronises for set-up: `lanes` (1..32) search lanes sized for batches of up to max_nq queries
  * with ef <= max_ef and k <= max_k (streams, events, per-query arrays, overflow tables, push
  * logs, pinned staging buffers for the host-pointer entry points), the padded adjacency, the
  * shared scratch pool of the heap-exact kernel, and one empty launch of the search kernels on
  * every lane's stream (code objects loaded, hardware queues created).  Call it after
- * isl_index_upload + a provider setter.  The reference has no such step (its search allocates
+ * isl_index_upload + a provider setter.  Lanes run on a per-device pool of at most 16 HIP streams
+ * (ISL_MAX_STREAMS; a card serves about that many hardware queues side by side and the rate
+ * collapses beyond): lanes past the pool's size share streams, their calls queue in stream order.
+ * The reference has no such step (its search allocates
  * per call, leann.rs:903-908); without it the first calls on each lane do this work lazily and
  * report it in isl_search_stats::allocations. */
 isl_status isl_index_prepare(isl_index* idx, uint64_t max_nq, uint64_t max_ef, uint64_t max_k,
@@ -230,7 +233,7 @@ isl_status isl_search_batch(const isl_index* idx, const float* queries, uint64_t
 /* Pipelined form of isl_search_batch: copies `queries` into the lane's pinned staging buffer
  * (they may be reused as soon as the call returns), enqueues H2D copy, search and D2H copies on
  * the lane's stream and returns.  out_ids / out_dist / out_count must stay valid until
- * isl_search_wait[_stats](*token) has returned; they are written there.  Up to 16 calls may be
+ * isl_search_wait[_stats](*token) has returned; they are written there.  Up to 32 calls may be
  * in flight.  token 0 = answered immediately (empty index, nq == 0). */
 isl_status isl_search_batch_async(const isl_index* idx, const float* queries, uint64_t nq, uint64_t d,
                                   uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dist,
@@ -242,7 +245,7 @@ isl_status isl_search_batch_device(const isl_index* idx, const float* d_queries,
                                    uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_out_ids,
                                    float* d_out_dist, uint32_t* d_out_count, void* stream);
 /* Asynchronous form: enqueues the search on one of the index's private streams (ordered after
- * the work already enqueued on `stream`) and returns at once; up to 16 searches may be in
+ * the work already enqueued on `stream`) and returns at once; up to 32 searches may be in
  * flight, so consecutive batches overlap and the slowest queries of one batch no longer idle
  * the chip.  Outputs are valid and the per-query status is reported once isl_search_wait
  * returns for *token (token 0 = the call was answered immediately).  An index with the recompute
@@ -362,7 +365,7 @@ void isl_shard_group_free(isl_shard_group* grp);
 
 /* The searcher of one rank: `shard` is this rank's LeannIndex over its id range (resident, provider
  * attached; borrowed, must outlive the searcher).  id_base[r] = first global id of rank r; NULL =
- * even ranges of n_total, rank r owns [r*n_total/R, (r+1)*n_total/R).  Up to `depth` (1..16)
+ * even ranges of n_total, rank r owns [r*n_total/R, (r+1)*n_total/R).  Up to `depth` (1..32)
  * batches in flight. */
 typedef struct isl_sharded_searcher isl_sharded_searcher;
 isl_status isl_sharded_searcher_new(const isl_index* shard, isl_shard_group* grp, uint64_t n_total,
@@ -559,7 +562,7 @@ isl_status isl_search_two_level_batch_device(const isl_index* idx, const float* 
                                              uint64_t d, uint64_t k, uint64_t ef, float rerank_ratio,
                                              uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count,
                                              void* stream);
-/* Asynchronous form (see isl_search_batch_device_async): up to 16 calls in flight on the index's
+/* Asynchronous form (see isl_search_batch_device_async): up to 32 calls in flight on the index's
  * lanes, completed with isl_search_wait[_stats](*token).  The call runs on a host thread of the
  * library's (a query whose queue window was too small is re-run with a larger one before the call
  * completes), so isl_search_stream_wait for such a token waits on the host. */

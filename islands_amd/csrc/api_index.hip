@@ -91,7 +91,8 @@ void free_workspace(SearchWorkspace& ws) {
   if (ws.ev0) (void)hipEventDestroy(ws.ev0);
   if (ws.ev1) (void)hipEventDestroy(ws.ev1);
   if (ws.ev_in) (void)hipEventDestroy(ws.ev_in);
-  if (ws.stream) (void)hipStreamDestroy(ws.stream);
+  if (ws.ev_done) (void)hipEventDestroy(ws.ev_done);
+  // (ws.stream belongs to the device's stream pool)
   ws = SearchWorkspace{};
 }
 

@@ -80,8 +80,8 @@ struct SearchWorkspace {
   float* h_dist = nullptr;
   uint32_t* h_count = nullptr;
   uint64_t h_out_slots = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_in = nullptr;
+  hipStream_t stream = nullptr;  // from the device's stream pool (search.hip): shared, never destroyed here
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_in = nullptr, ev_done = nullptr;
   // call in flight on this lane (claim .. release)
   bool busy = false;           // under isl_index::mu
   bool waiting = false;        // a thread is inside isl_search_wait for this lane (under mu)
@@ -142,7 +142,7 @@ struct SearchWorkspace {
   isl_search_stats stats{};      // statistics of the call that finished last on this lane
 };
 
-constexpr int kSearchLanes = 16;  // independent workspaces = searches that may be in flight
+constexpr int kSearchLanes = 32;  // independent workspaces = searches that may be in flight (on <= 16 pooled streams)
 
 // Scratch of the heap-exact kernel, ONE pool per index shared by every lane: a workgroup that
 // finds work in its redo queue claims a free slot (lock word per slot), so concurrent searches

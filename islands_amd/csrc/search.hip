@@ -147,11 +147,39 @@ uint32_t push_log_cap(uint32_t ef) { return std::max<uint32_t>(1024, 12 * ef); }
 
 // Streams, events, per-query arrays, overflow table, push log of one lane, sized for nq queries
 // on `slots` resident waves.
-isl_status ensure_lane_stream(isl::SearchWorkspace& ws) {
+// The lanes' streams come from ONE pool per device and process: a card serves only so many hardware
+// queues side by side, and past about twenty streams in use the search rate collapses (24 streams on
+// one card: 0.39 M queries/s where 16 reach 1.4 M; two processes with 12 each: 16 k against 145 k --
+// DESIGN section 4).  More lanes than pool streams simply share: lane i of any index runs on stream
+// i mod pool size, its calls in stream order behind the other lane's, every call waited for through
+// its own event.  ISL_MAX_STREAMS (1..32, default 16) sizes the pool -- processes that share a card
+// should divide the sixteen between them.  Pool streams live as long as the process.
+hipStream_t pool_stream(int32_t device, uint32_t lane, bool* created) {
+  static std::mutex mu;
+  static hipStream_t pool[64][32];
+  static const uint32_t size = [] {
+    const char* e = getenv("ISL_MAX_STREAMS");
+    const int v = e ? atoi(e) : 16;
+    return (uint32_t)std::min(std::max(v, 1), 32);
+  }();
+  *created = false;
+  if (device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  hipStream_t& st = pool[device][lane % size];
+  if (!st) {
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }
+    else *created = true;
+  }
+  return st;
+}
+
+isl_status ensure_lane_stream(const isl_index* idx, isl::SearchWorkspace& ws) {
   if (ws.stream) return ISL_OK;
-  hipStream_t st = nullptr;
-  ISL_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  ws.alloc_events++;
+  bool created = false;
+  hipStream_t st = pool_stream(idx->device, (uint32_t)(&ws - idx->ws), &created);
+  if (!st) return isl::fail(ISL_ERR_DEVICE, "hipStreamCreate failed for a search lane");
+  if (created) ws.alloc_events++;
+  if (!ws.ev_done) { ISL_HIP(hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming)); ws.alloc_events++; }
   if (!ws.ev0) { ISL_HIP(hipEventCreate(&ws.ev0)); ws.alloc_events++; }
   if (!ws.ev1) { ISL_HIP(hipEventCreate(&ws.ev1)); ws.alloc_events++; }
   if (!ws.ev_in) { ISL_HIP(hipEventCreateWithFlags(&ws.ev_in, hipEventDisableTiming)); ws.alloc_events++; }
@@ -164,9 +192,9 @@ isl_status ensure_lane_stream(isl::SearchWorkspace& ws) {
   return ISL_OK;
 }
 
-isl_status prepare_workspace(isl::SearchWorkspace& ws, uint32_t nq, uint32_t slots,
+isl_status prepare_workspace(const isl_index* idx, isl::SearchWorkspace& ws, uint32_t nq, uint32_t slots,
                              uint32_t plog_cap) {
-  ISL_TRY(ensure_lane_stream(ws));
+  ISL_TRY(ensure_lane_stream(idx, ws));
   if (ws.h_cap < nq) {
     if (ws.h_status) (void)hipHostFree(ws.h_status);
     if (ws.h_ctr) (void)hipHostFree(ws.h_ctr);
@@ -421,7 +449,7 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
   // per-slot state is indexed by blockIdx.x < min(nq, slots) -- by the query when it can come back on
   // another wave
   if (!warm)
-    ISL_TRY(prepare_workspace(ws, (uint32_t)nq,
+    ISL_TRY(prepare_workspace(idx, ws, (uint32_t)nq,
                               (uint32_t)(idx->recompute ? nq : std::min<uint64_t>(nq, std::max(std::max(slots, slots_q), cg.tl_slots_q))),
                               plog_cap));
   if (!idx->pool.slots || ((use_fast || (tl && idx->max_degree <= 128)) && !idx->d_ell && idx->d_off && idx->num_nodes)) {
@@ -617,6 +645,8 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
   if (warm) return ISL_OK;
 
   ISL_TRY(publish(ws, nq, k, st));
+  // the call's own completion event: lanes may share a stream, and a caller's stream carries its other work
+  if (ws.ev_done) ISL_HIP(hipEventRecord(ws.ev_done, st));
   ws.enqueued = true;
   ws.nq_inflight = nq;
   ws.k_inflight = k;
@@ -666,7 +696,8 @@ isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws, uint32_
   ws.enqueued = false;
   const uint64_t nq = ws.nq_inflight;
   const bool use_fast = ws.fast_inflight;
-  ISL_HIP(hipStreamSynchronize(ws.st_inflight));
+  if (ws.ev_done) ISL_HIP(hipEventSynchronize(ws.ev_done));
+  else ISL_HIP(hipStreamSynchronize(ws.st_inflight));
   const uint32_t* status = ws.h_status;
   const uint32_t* ctr = ws.h_ctr;
   const uint32_t* head = ws.h_head;
@@ -938,7 +969,7 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
   const bool resumable = tl || cg0.use_fast;
   ISL_TRY(prepare_recompute(ws, nq, tl ? isl_launch::tl_state_words(cg0.ef, cg0.tl_wcap, cg0.fg.hbits)
                                        : resumable ? isl_launch::fast_state_words(S0, cg0.fg.hbits) : 1));
-  ISL_TRY(ensure_lane_stream(ws));
+  ISL_TRY(ensure_lane_stream(idx, ws));
   hipStream_t st = mode == StreamMode::USER ? user_stream : ws.stream;
   if (!idx->keep_rows) {  // every call starts from an empty cache: each node is encoded once per call
     ISL_HIP(hipMemsetAsync(idx->d_slot_of, 0xFF, (idx->nvec + 1) * 4, st));
@@ -1145,9 +1176,9 @@ struct LaneGuard {
 
 // host-pointer calls: the queries go through the lane's pinned buffer, from where a kernel pulls
 // them into HBM; the answers come back with the publish kernel (ws.publish_results)
-isl_status host_stage_in(isl::SearchWorkspace& ws, const float* queries, uint64_t nq, uint64_t d, uint64_t k) {
+isl_status host_stage_in(const isl_index* idx, isl::SearchWorkspace& ws, const float* queries, uint64_t nq, uint64_t d, uint64_t k) {
   ISL_TRY(prepare_host_staging(ws, nq, d, k));
-  ISL_TRY(ensure_lane_stream(ws));
+  ISL_TRY(ensure_lane_stream(idx, ws));
   memcpy(ws.h_q, queries, nq * d * 4);
   const uint64_t bytes = nq * d * 4;
   if (bytes % 16 == 0)
@@ -1299,7 +1330,7 @@ isl_status isl_index_prepare(isl_index* idx, uint64_t max_nq, uint64_t max_ef, u
   } release_all{idx, lanes};
   for (int i = 0; i < lanes; ++i) {
     isl::SearchWorkspace& ws = idx->ws[i];
-    ISL_TRY(prepare_workspace(ws, (uint32_t)max_nq, idx->recompute ? (uint32_t)max_nq : ovf_slots,
+    ISL_TRY(prepare_workspace(idx, ws, (uint32_t)max_nq, idx->recompute ? (uint32_t)max_nq : ovf_slots,
                               push_log_cap((uint32_t)max_ef)));
     ISL_TRY(prepare_host_staging(ws, max_nq, d, std::max<uint64_t>(max_k, 1)));
     if (idx->recompute) {
@@ -1376,7 +1407,7 @@ isl_status isl_search_batch_device_async(const isl_index* idx, const float* d_qu
   if (idx->recompute) {
     // the provider works through the batch in rounds (search, encode what was missed, resume): the
     // synchronous form on a thread of its own, ordered after the caller's stream
-    ISL_TRY(ensure_lane_stream(*ws));
+    ISL_TRY(ensure_lane_stream(idx, *ws));
     ISL_HIP(hipEventRecord(ws->ev_in, (hipStream_t)stream));
     ISL_HIP(hipStreamWaitEvent(ws->stream, ws->ev_in, 0));
     start_worker(idx, ws, [=]() {
@@ -1409,7 +1440,7 @@ isl_status isl_search_batch_async(const isl_index* idx, const float* queries, ui
   isl::SearchWorkspace* ws = claim_lane(idx);
   if (!ws) return no_lane();
   LaneGuard guard{idx, ws};
-  ISL_TRY(host_stage_in(*ws, queries, nq, d, k));
+  ISL_TRY(host_stage_in(idx, *ws, queries, nq, d, k));
   if (idx->recompute) {
     start_worker(idx, ws, [=]() {
       return search_sync(idx, *ws, ws->q_stage, nq, d, k, ef, ws->ids_stage, ws->dist_stage, ws->count_stage, nullptr,
@@ -1504,7 +1535,7 @@ static isl_status search_batch_host(const isl_index* idx, const float* queries, 
   if (!wsp) return no_lane();
   LaneGuard guard{idx, wsp};
   isl::SearchWorkspace& ws = *wsp;
-  ISL_TRY(host_stage_in(ws, queries, nq, d, k));
+  ISL_TRY(host_stage_in(idx, ws, queries, nq, d, k));
   const isl_status st = search_sync(idx, ws, ws.q_stage, nq, d, k, ef, ws.ids_stage, ws.dist_stage, ws.count_stage,
                                     nullptr, StreamMode::OWN, tl);
   note_last_stats(idx, ws.stats);
@@ -1602,7 +1633,7 @@ isl_status isl_search_two_level_batch_device_async(const isl_index* idx, const f
   isl::SearchWorkspace* ws = claim_lane(idx);
   if (!ws) return no_lane();
   LaneGuard guard{idx, ws};
-  ISL_TRY(ensure_lane_stream(*ws));
+  ISL_TRY(ensure_lane_stream(idx, *ws));
   ISL_HIP(hipEventRecord(ws->ev_in, (hipStream_t)stream));
   ISL_HIP(hipStreamWaitEvent(ws->stream, ws->ev_in, 0));
   const TwoLevelCall tl{rerank_ratio};

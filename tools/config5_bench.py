@@ -42,9 +42,16 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--ef", type=int, default=128)
     ap.add_argument("--pq-m", type=int, default=64)
-    ap.add_argument("--ratio", type=float, default=0.3, help="re-rank ratio of the two-level search")
+    ap.add_argument("--ratio", type=float, default=0.3, help="re-rank ratio of the two-level search's headline point")
     ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--depth", type=int, default=6)
+    ap.add_argument("--distinct-batches", type=int, default=0,
+                    help="query batches the steps cycle through, each with its own ground truth (0 = steps + warmup: "
+                         "no two launches of the run traverse the same queries)")
+    ap.add_argument("--tl-steps", type=int, default=8, help="batches per operating point of the two-level sweep")
+    ap.add_argument("--tl-ratios", default="0.3,0.5,0.7,0.85,1.0")
+    ap.add_argument("--tl-efs", default="128,256")
     ap.add_argument("--skip-two-level", action="store_true")
     ap.add_argument("--graph-only", action="store_true", help="stop after the graph (harness check)")
     a = ap.parse_args()
@@ -61,42 +68,52 @@ def main():
         x16[o:o + c] = synth.make_rows(N, d, o, c, device=dev).to(torch.bfloat16)
     torch.cuda.synchronize()
     log(f"{N} x {d} bf16 rows ({N * d * 2 / 1e9:.1f} GB) in {time.time() - t0:.1f}s")
-    q = synth.make_rows(N, d, 0, nq, device=dev, query=True)
-    q16 = q.to(torch.bfloat16).contiguous()
-    qf = q16.to(torch.float32).contiguous()  # the queries' exact f32 images (what the traversal takes)
+    nb_batches = a.distinct_batches if a.distinct_batches > 0 else a.steps + a.warmup
+    q16s, qfs = [], []
+    for b in range(nb_batches):
+        qb = synth.make_rows(N, d, b * nq, nq, device=dev, query=True).to(torch.bfloat16).contiguous()
+        q16s.append(qb)
+        qfs.append(qb.to(torch.float32).contiguous())  # the queries' exact f32 images (what the traversal takes)
 
     # ---- the dense side: every (query, row) distance as a bf16 GEMM, block by block, + exact top-k
+    # (one pass per distinct query batch: it is also that batch's ground truth)
     t0 = time.time()
     block = 65536
     out = torch.empty((nq, block), dtype=torch.float32, device=dev)
-    best_d = torch.full((nq, k), float("inf"), device=dev)
-    best_i = torch.zeros((nq, k), dtype=torch.int64, device=dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     gemm_ms = 0.0
-    for o in range(0, N, block):
-        c = min(block, N - o)
-        torch.cuda.synchronize()
-        ev0.record()
-        _check(lib.isl_distance_matrix_bf16(0, C.c_void_p(q16.data_ptr()), nq, C.c_void_p(x16[o:o + c].data_ptr()), c, d,
-                                            C.c_void_p(out.data_ptr()), ia.MEM_DEVICE, 0, None))
-        ev1.record()
-        torch.cuda.synchronize()
-        gemm_ms += ev0.elapsed_time(ev1)
-        dd, ii = torch.topk(out.view(-1)[:nq * c].view(nq, c), k, dim=1, largest=False)  # [nq][c], dense
-        cat_d = torch.cat([best_d, dd], 1)
-        cat_i = torch.cat([best_i, ii + o], 1)
-        sel = torch.topk(cat_d, k, dim=1, largest=False).indices
-        best_d, best_i = torch.gather(cat_d, 1, sel), torch.gather(cat_i, 1, sel)
-    gemm_flops = 2.0 * nq * N * d
+    truths = []
+    for b, q16 in enumerate(q16s):
+        best_d = torch.full((nq, k), float("inf"), device=dev)
+        best_i = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+        for o in range(0, N, block):
+            c = min(block, N - o)
+            torch.cuda.synchronize()
+            ev0.record()
+            _check(lib.isl_distance_matrix_bf16(0, C.c_void_p(q16.data_ptr()), nq, C.c_void_p(x16[o:o + c].data_ptr()), c, d,
+                                                C.c_void_p(out.data_ptr()), ia.MEM_DEVICE, 0, None))
+            ev1.record()
+            torch.cuda.synchronize()
+            gemm_ms += ev0.elapsed_time(ev1)
+            dd, ii = torch.topk(out.view(-1)[:nq * c].view(nq, c), k, dim=1, largest=False)  # [nq][c], dense
+            cat_d = torch.cat([best_d, dd], 1)
+            cat_i = torch.cat([best_i, ii + o], 1)
+            sel = torch.topk(cat_d, k, dim=1, largest=False).indices
+            best_d, best_i = torch.gather(cat_d, 1, sel), torch.gather(cat_i, 1, sel)
+        truths.append(best_i)
+        if b % 4 == 0:
+            log(f"ground truth of batch {b + 1} / {nb_batches} ({time.time() - t0:.0f}s)")
+    gemm_flops = 2.0 * nq * N * d * nb_batches
     gemm_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12
-    log(f"distance GEMM over all rows: {gemm_ms:.1f} ms of kernels = {gemm_tflops:.0f} TFLOP/s; "
+    log(f"distance GEMM over all rows, {nb_batches} query batches: {gemm_ms:.1f} ms of kernels = {gemm_tflops:.0f} TFLOP/s; "
         f"with top-k {time.time() - t0:.1f}s")
     del out
 
     # ---- graph (harness) on the bf16 rows
     t0 = time.time()
-    # (every harness GEMM in float32: the bf16 GEMMs torch picks for these shapes ended in a GPU memory
-    # access fault at d = 4096, at 1M and at 10M rows alike)
+    # (every harness GEMM on float32 operands and every per-chunk tensor within 1 GiB: round 2 lost a box
+    # to a GPU memory access fault inside this builder on bf16 operands at d = 4096 -- tools/synth.py,
+    # _CHUNK_BYTES, has what is known about it)
     off, nb, entry = synth.build_graph(x16, m0=60, precise=True)
     torch.cuda.synchronize()
     gst = synth.graph_stats(off)
@@ -123,67 +140,91 @@ def main():
     torch.cuda.empty_cache()
 
     depth = a.depth
-    idx.prepare(nq, ef, k, depth)
+    idx.prepare(nq, max(ef, max(int(e) for e in a.tl_efs.split(","))), k, depth)
     outs = [(torch.zeros((nq, k), dtype=torch.int64, device=dev), torch.zeros((nq, k), dtype=torch.float32, device=dev),
              torch.zeros(nq, dtype=torch.int32, device=dev)) for _ in range(depth)]
 
-    def recall(ids, cnt):
-        return synth.recall_at_k(ids, cnt, best_i)
+    def pipelined(first, count, submit):
+        """`count` steps with `depth` calls in flight; step s answers query batch s % nb_batches; returns the summed
+        counters and the recall over every step's answers against that batch's own ground truth."""
+        agg = {"expansions": 0, "edges": 0, "evals": 0, "pushes": 0, "queries": 0, "kernel_ms": 0.0, "exact_path": 0}
+        hits, pend = [], []
 
-    # ---- traversal over the bf16 rows (LeannIndex::search), `depth` batches in flight
-    def run(steps):
-        agg = {"expansions": 0, "edges": 0, "evals": 0, "queries": 0, "kernel_ms": 0.0, "exact_path": 0}
-        pend = []
-        for s in range(steps):
-            o = outs[s % depth]
-            pend.append(idx.search_batch_device_async(qf.data_ptr(), nq, d, k, ef, o[0].data_ptr(), o[1].data_ptr(),
-                                                      o[2].data_ptr()))
-            if len(pend) >= depth:
-                st = idx.wait_stats(pend.pop(0))
-                for f in agg:
-                    agg[f] += st[f]
-        while pend:
-            st = idx.wait_stats(pend.pop(0))
+        def finish():
+            s_, tok = pend.pop(0)
+            st = idx.wait_stats(tok)
             for f in agg:
                 agg[f] += st[f]
-        return agg
+            o = outs[s_ % depth]
+            hits.append(synth.recall_at_k(o[0], o[2], truths[s_ % nb_batches]))
 
-    run(2)
+        for s_ in range(first, first + count):
+            o = outs[s_ % depth]
+            pend.append((s_, submit(qfs[s_ % nb_batches], o)))
+            if len(pend) >= depth:
+                finish()
+        while pend:
+            finish()
+        return agg, float(np.mean(hits))
+
+    # ---- traversal over the bf16 rows (LeannIndex::search), `depth` batches in flight
+    def plain(efv):
+        return lambda q_, o: idx.search_batch_device_async(q_.data_ptr(), nq, d, k, efv, o[0].data_ptr(), o[1].data_ptr(),
+                                                           o[2].data_ptr())
+
+    pipelined(0, a.warmup, plain(ef))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    agg = run(a.steps)
+    agg, rec = pipelined(a.warmup, a.steps, plain(ef))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    rec = recall(outs[(a.steps - 1) % depth][0], outs[(a.steps - 1) % depth][2])
     bytes_total = agg["evals"] * d * 2 + 4 * agg["edges"] + 8 * agg["expansions"] + agg["queries"] * (4 * d + 12 * k)
     hbm_gbs = bytes_total / dt / 1e9
     log(f"traversal: {a.steps * nq / dt:.0f} q/s, recall {rec:.4f}, {hbm_gbs:.0f} GB/s algorithmic")
 
     if not a.skip_two_level:
-        o = outs[0]
-        idx.search_two_level_batch_device(qf.data_ptr(), nq, d, k, ef, a.ratio, o[0].data_ptr(), o[1].data_ptr(),
-                                          o[2].data_ptr())
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            idx.search_two_level_batch_device(qf.data_ptr(), nq, d, k, ef, a.ratio, o[0].data_ptr(), o[1].data_ptr(),
-                                              o[2].data_ptr())
-        torch.cuda.synchronize()
-        dtl = (time.perf_counter() - t0) / reps
-        st = idx.last_stats()
-        res_tl = {"value": round(nq / dtl, 1), "unit": "queries/s", "ms_per_batch": round(dtl * 1e3, 2),
-                  "rerank_ratio": a.ratio, "pq": {"m": a.pq_m, "K": 256, "dsub": d // a.pq_m},
-                  "exact_evals_per_query": round(st["evals"] / nq, 1),
-                  "approx_evals_per_query": round(st["pushes"] / nq, 1),
-                  "recall_at_10": round(recall(o[0], o[2]), 4),
-                  "note": "build_distance_tables for the batch + two-level traversal (extension, DESIGN 3.6), one call at a time"}
+        # Operating points of the PQ re-rank path (build_distance_tables for the batch + two-level search,
+        # extension, DESIGN 3.6), `depth` calls in flight like the plain traversal, every step its own queries.
+        # Algorithmic bytes per query: promoted rows V * d * 2 + codes A * m * 2 + 4 E + 8 H + 4 d + 12 k.
+        def two_level(efv, ratio):
+            return lambda q_, o: idx.search_two_level_batch_device_async(q_.data_ptr(), nq, d, k, efv, ratio, o[0].data_ptr(),
+                                                                         o[1].data_ptr(), o[2].data_ptr())
+
+        points = []
+        for efv in [int(e) for e in a.tl_efs.split(",")]:
+            for ratio in [float(r) for r in a.tl_ratios.split(",")]:
+                pipelined(0, 2, two_level(efv, ratio))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ag, rc = pipelined(2, a.tl_steps, two_level(efv, ratio))
+                torch.cuda.synchronize()
+                dtl = time.perf_counter() - t0
+                nqq = ag["queries"]
+                by = ag["evals"] * d * 2 + ag["pushes"] * a.pq_m * 2 + 4 * ag["edges"] + 8 * ag["expansions"] + nqq * (4 * d + 12 * k)
+                pt = {"ef": efv, "rerank_ratio": ratio, "value": round(nqq / dtl, 1), "unit": "queries/s",
+                      "recall_at_10": round(rc, 4), "exact_evals_per_query": round(ag["evals"] / nqq, 1),
+                      "approx_evals_per_query": round(ag["pushes"] / nqq, 1),
+                      "hops_per_query": round(ag["expansions"] / nqq, 1),
+                      "algorithmic_gbs": round(by / dtl / 1e9, 1), "hbm_frac": round(by / dtl / 1e9 / 8000.0, 4)}
+                points.append(pt)
+                log(f"two-level {pt}")
+        good = [p_ for p_ in points if p_["recall_at_10"] >= 0.95]
+        best = max(good, key=lambda p_: p_["value"]) if good else None
+        head = next((p_ for p_ in points if p_["ef"] == ef and abs(p_["rerank_ratio"] - a.ratio) < 1e-6), points[0])
+        res_tl = dict(head)
+        res_tl.update({"pq": {"m": a.pq_m, "K": 256, "dsub": d // a.pq_m}, "calls_in_flight": depth,
+                       "steps_per_point": a.tl_steps, "operating_points": points,
+                       "fastest_point_with_recall_at_least_0.95": best,
+                       "plain_traversal_for_comparison": {"value": round(a.steps * nq / dt, 1), "recall_at_10": round(rec, 4),
+                                                          "evals_per_query": round(agg["evals"] / agg["queries"], 1)},
+                       "note": "build_distance_tables for the batch + two-level traversal (extension, DESIGN 3.6), pipelined "
+                               "through isl_search_two_level_batch_device_async"})
 
     print(json.dumps({
         "metric": "BASELINE config 5: 10M x 4096 bf16, query batch 4096 (distance GEMM + PQ re-rank + traversal)",
         "value": round(a.steps * nq / dt, 1), "unit": "queries/s", "recall_at_10": round(rec, 4),
         "config": {"workload": f"{N} x {d} bf16 rows resident in HBM, query batch {nq}, k={k}, ef={ef}, cosine, "
-                               f"{depth} batches in flight", "graph": gst,
+                               f"{depth} batches in flight", "graph": gst, "distinct_batches": nb_batches,
                    "per_query": {"expansions": round(agg["expansions"] / agg["queries"], 1),
                                  "edges": round(agg["edges"] / agg["queries"], 1),
                                  "evals": round(agg["evals"] / agg["queries"], 1)},
@@ -194,7 +235,8 @@ def main():
         "roofline_mfma": {"bound": "mfma", "achieved": round(gemm_tflops, 1), "peak": 2500.0, "unit": "TFLOP/s",
                           "frac": round(gemm_tflops / 2500.0, 4), "kernel": "gemm_tn_bf16_dma<256x256> (isl_distance_matrix_bf16)",
                           "flops": gemm_flops, "kernel_ms_total": round(gemm_ms, 1),
-                          "note": f"every (query, row) cosine distance of the batch: {nq} x {N} x {d}, in blocks of {block} rows"},
+                          "note": f"every (query, row) cosine distance of {nb_batches} query batches: {nq} x {N} x {d} each, in "
+                                  f"blocks of {block} rows"},
         "two_level": res_tl,
     }))
 

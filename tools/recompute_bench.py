@@ -94,6 +94,15 @@ def main():
                     help="two-level search with a PQ filter (extension): promote this share of the "
                          "approximate queue to exact recomputation")
     ap.add_argument("--pq-m", type=int, default=96)
+    ap.add_argument("--two-level-auto", action="store_true",
+                    help="choose the two-level operating point: sweep (ratio, ef) over the in-memory provider holding the "
+                         "same embeddings (identical traversals, no encoding) and take the point with the fewest exact "
+                         "evaluations per query among those with recall@10 >= 0.95; then run it over the recompute provider")
+    ap.add_argument("--also-plain", action="store_true", help="with --two-level[-auto]: the plain search over the recompute "
+                    "provider too (at the first ef of --ef-list / --ef that reaches recall 0.95 in memory)")
+    ap.add_argument("--warm", action="store_true",
+                    help="afterwards, with keep_rows = 1 (the row cache survives the call): a first batch, a second batch "
+                         "of other queries, and the first batch again")
     ap.add_argument("--check-in-memory", action="store_true",
                     help="also run the batch over the in-memory provider holding the same embeddings and compare bits")
     args = ap.parse_args()
@@ -146,70 +155,133 @@ def main():
     ti, _ = synth.brute_force_topk(x, q, args.k)
     qh = q.cpu().numpy()
 
-    mem_res = None
-    if args.check_in_memory:
+    tih = ti.cpu().numpy()
+    flops_note = "encoder flops of the call / wall time of the call (rounds, gathers and traversal included); " \
+                 "layers*(24 h^2 L + 4 L^2 h) flops per node"
+    mode_label = "bf16 Linear layers, float32 accumulation" if args.bf16 else "float32 MFMA"
+    peak = 2500.0 if args.bf16 else MFMA_F32_PEAK_TFLOPS
+
+    def recall_of(ids, cnt, truth=None):
+        truth = tih if truth is None else truth
+        return sum(len(set(ids[i, :cnt[i]].tolist()) & set(truth[i].tolist())) for i in range(ids.shape[0])) / (ids.shape[0] * args.k)
+
+    # the in-memory provider over the same embeddings: reference answers for the equality check and,
+    # with --two-level-auto, the cheap place to look for the operating point (same traversal, no encoding)
+    midx = None
+    if args.check_in_memory or args.two_level_auto or args.also_plain:
         midx = ia.LeannIndex.from_device_csr(off.data_ptr(), nb.data_ptr(), N, entry, h)
         midx.set_embeddings(None, device_ptr=x.data_ptr(), n=N, d=h)
-        mem_res = midx.search_batch(qh, args.k, args.ef)
-        mem_stats = midx.last_stats()
-        del midx
-    idx = ia.LeannIndex.from_device_csr(off.data_ptr(), nb.data_ptr(), N, entry, h)
-    idx.set_recompute_provider(enc, device_ptr=tok16.data_ptr(), n=N, L=L, keep_rows=False, cache_rows=args.cache_rows)
     pq = None
-    if args.two_level > 0:
+    ratio = args.two_level
+    if args.two_level > 0 or args.two_level_auto:
+        t0 = time.time()
         cb, codes = synth.train_pq(x, args.pq_m)
         pq = ia.ProductQuantizer(h, cb.cpu().numpy())
+        log(f"PQ m={args.pq_m} trained, {N} rows encoded in {time.time() - t0:.1f}s")
+    efs = [int(e) for e in args.ef_list.split(",") if e] or [args.ef]
+    ef_tl, sweep = efs[0], None
+    if args.two_level_auto:
+        midx.set_pq_codes(pq, None, device_ptr=codes.data_ptr(), n=N)
+        sweep = []
+        for efv in sorted(set(efs + [128, 192, 256, 384])):
+            for a_ in (0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0):
+                ids, dist, cnt = midx.search_two_level_batch(qh, args.k, efv, a_)
+                st = midx.last_stats()
+                sweep.append({"ef": efv, "ratio": a_, "recall_at_10": round(recall_of(ids, cnt), 4),
+                              "exact_evals_per_query": round(st["evals"] / args.nq, 1),
+                              "approx_evals_per_query": round(st["pushes"] / args.nq, 1)})
+        good = [p_ for p_ in sweep if p_["recall_at_10"] >= 0.95]
+        if not good:
+            log("no two-level point reaches recall 0.95 on these embeddings; taking ratio 1.0 at the largest ef")
+            good = [max(sweep, key=lambda p_: (p_["recall_at_10"]))]
+        best = min(good, key=lambda p_: p_["exact_evals_per_query"])
+        ratio, ef_tl = best["ratio"], best["ef"]
+        log(f"two-level operating point from the in-memory sweep: {best}")
+    ef_plain = None
+    if args.also_plain or (pq is None):
+        ef_plain = efs[-1]
+        if midx is not None:
+            for efv in efs:
+                ids, dist, cnt = midx.search_batch(qh, args.k, efv)
+                if recall_of(ids, cnt) >= 0.95:
+                    ef_plain = efv
+                    break
+
+    idx = ia.LeannIndex.from_device_csr(off.data_ptr(), nb.data_ptr(), N, entry, h)
+    idx.set_recompute_provider(enc, device_ptr=tok16.data_ptr(), n=N, L=L, keep_rows=False, cache_rows=args.cache_rows)
+    if pq is not None:
         idx.set_pq_codes(pq, None, device_ptr=codes.data_ptr(), n=N)
-        del codes
-    del x
-    torch.cuda.empty_cache()
     torch.cuda.synchronize()
     log("graph and index ready, searching")
-    tih = ti.cpu().numpy()
-    efs = [int(e) for e in args.ef_list.split(",") if e] or [args.ef]
-    for ef in efs:
+
+    def run(label, queries, truth, ef, tl_ratio, check=False, extra=None):
         t0 = time.time()
-        if pq is not None:
-            ids, dist, cnt = idx.search_two_level_batch(qh, args.k, ef, args.two_level)
+        if tl_ratio:
+            ids, dist, cnt = idx.search_two_level_batch(queries, args.k, ef, tl_ratio)
         else:
-            ids, dist, cnt = idx.search_batch(qh, args.k, ef)
+            ids, dist, cnt = idx.search_batch(queries, args.k, ef)
         dt = time.time() - t0
         st = idx.last_stats()
-        hit = sum(len(set(ids[i, :cnt[i]].tolist()) & set(tih[i].tolist())) for i in range(args.nq))
+        nq_ = queries.shape[0]
         enc_tflops = st["encoded_nodes"] * flops_per_node / dt / 1e12
-        mode_label = "bf16 Linear layers, float32 accumulation" if args.bf16 else "float32 MFMA"
         res = {
-            "metric": "queries/s, recompute provider (BASELINE config 3)",
-            "value": round(args.nq / dt, 2), "unit": "queries/s",
+            "metric": "queries/s, recompute provider (BASELINE config 3)", "run": label,
+            "value": round(nq_ / dt, 2), "unit": "queries/s",
             "config": {"workload": f"{N} nodes x {L} tokens, 6-layer encoder hidden 768 ({mode_label}), "
-                                   f"query batch {args.nq}, k={args.k}, ef={ef}, cosine",
-                       "search": (f"two-level, rerank ratio {args.two_level}, PQ m={args.pq_m} K=256"
-                                  if pq is not None else "LeannIndex::search"),
+                                   f"query batch {nq_}, k={args.k}, ef={ef}, cosine",
+                       "search": (f"two-level, rerank ratio {tl_ratio}, PQ m={args.pq_m} K=256" if tl_ratio else "LeannIndex::search"),
                        "graph": gst},
-            "recall_at_10": round(hit / (args.nq * args.k), 4),
+            "recall_at_10": round(recall_of(ids, cnt, truth), 4),
             "seconds": round(dt, 2), "rounds": st["recompute_rounds"],
-            "evals": st["evals"], "approx_evals": st["pushes"] if pq is not None else 0,
-            "encoded_nodes": st["encoded_nodes"],
+            "evals": st["evals"], "approx_evals": st["pushes"] if tl_ratio else 0,
+            "encoded_nodes": st["encoded_nodes"], "encoded_nodes_per_query": round(st["encoded_nodes"] / nq_, 1),
             "search_kernel_ms_all_rounds": round(st["kernel_ms"], 1),
             "provider_hbm_bytes": {"row_cache_and_slot_map": idx.recompute_cache_bytes(), "token_table": N * L * 2,
-                                   "dense_table_would_be": N * h * 4},
-            "roofline": {"bound": "mfma", "achieved": round(enc_tflops, 1),
-                         "peak": 2500.0 if args.bf16 else MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(enc_tflops / (2500.0 if args.bf16 else MFMA_F32_PEAK_TFLOPS), 4),
-                         "note": "encoder flops of the call / wall time of the call (rounds, gathers and "
-                                 "traversal included); layers*(24 h^2 L + 4 L^2 h) flops per node"},
+                                   "pq_codes": (N * args.pq_m * 2 if pq is not None else 0), "dense_table_would_be": N * h * 4},
+            "roofline": {"bound": "mfma", "achieved": round(enc_tflops, 1), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(enc_tflops / peak, 4), "note": flops_note},
             "encode_all_nodes_seconds": round(t_all, 1),
             "encode_all_tflops": round(N * flops_per_node / t_all / 1e12, 1),
         }
-        if mem_res is not None and ef == args.ef:
+        if check and midx is not None:
+            if tl_ratio:
+                m_ids, m_dist, m_cnt = midx.search_two_level_batch(queries, args.k, ef, tl_ratio)
+            else:
+                m_ids, m_dist, m_cnt = midx.search_batch(queries, args.k, ef)
+            ms = midx.last_stats()
             res["equals_in_memory_provider"] = bool(
-                (mem_res[0] == ids).all() and (mem_res[1].view(np.uint32) == dist.view(np.uint32)).all()
-                and (mem_res[2] == cnt).all()
-                and all(mem_stats[f] == st[f] for f in ("expansions", "edges", "evals", "pushes")))
+                (m_ids == ids).all() and (m_dist.view(np.uint32) == dist.view(np.uint32)).all() and (m_cnt == cnt).all()
+                and all(ms[f] == st[f] for f in ("expansions", "edges", "evals", "pushes")))
+        if extra:
+            res.update(extra)
         print(json.dumps(res), flush=True)
-        log(f"ef={ef}: recall {res['recall_at_10']}, {dt:.1f}s")
-        if res["recall_at_10"] >= 0.95:
-            break
+        log(f"{label}: ef={ef} ratio={tl_ratio}: recall {res['recall_at_10']}, {dt:.1f}s, {res['encoded_nodes_per_query']} nodes/query")
+        return res
+
+    if pq is None:
+        for ef in efs:  # round 2's behaviour: the ef values in turn, stopping at the first that reaches 0.95
+            r = run("plain", qh, tih, ef, 0.0, check=args.check_in_memory and ef == args.ef)
+            if r["recall_at_10"] >= 0.95:
+                break
+    else:
+        if args.also_plain:
+            run("plain", qh, tih, ef_plain, 0.0, check=True)
+        run("two_level", qh, tih, ef_tl, ratio, check=True, extra={"in_memory_sweep": sweep} if sweep else None)
+    if args.warm:
+        # the row cache as an embedding cache that survives calls (keep_rows = 1): a first batch from an empty
+        # cache, a second batch of other queries, the first batch again
+        idx.set_recompute_provider(enc, device_ptr=tok16.data_ptr(), n=N, L=L, keep_rows=True, cache_rows=args.cache_rows)
+        if pq is not None:
+            idx.set_pq_codes(pq, None, device_ptr=codes.data_ptr(), n=N)
+        qnode2 = torch.randint(0, N, (args.nq,), generator=torch.Generator().manual_seed(47)).to(dev)
+        q2 = torch.empty((args.nq, h), dtype=torch.float32, device=dev)
+        embed_device(enc, path_tokens(qnode2, L, cfg["vocab_size"], 1000, 44, 4747), q2)
+        t2 = synth.brute_force_topk(x, q2, args.k)[0].cpu().numpy()
+        q2h = q2.cpu().numpy()
+        ef_w, r_w = (ef_tl, ratio) if pq is not None else (ef_plain, 0.0)
+        run("keep_rows: first batch, empty cache", qh, tih, ef_w, r_w)
+        run("keep_rows: second batch, other queries", q2h, t2, ef_w, r_w, check=True)
+        run("keep_rows: first batch again", qh, tih, ef_w, r_w, check=True)
 
 
 if __name__ == "__main__":
