@@ -245,6 +245,10 @@ def main():
                     help="query batches the steps cycle through, each with its own ground truth; default (0) = "
                          "steps + warmup, so that no two launches in flight (or anywhere in the run) traverse "
                          "the same queries (round 2 cycled 4 batches under 16 launches in flight)")
+    ap.add_argument("--rehearse-shard", default="", metavar="r/R",
+                    help="one GPU plays rank r of an R-rank sharded run of --nodes rows: it generates and indexes "
+                         "only that shard's rows and answers the batches over them (no exchange) -- what one rank of "
+                         "BASELINE config 4 (--nodes 100000000, 8 ranks) holds and does, measurable on one card")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous, one all-gather of a packed record over the process group and the JSON "
                          "line only (no GPU work): the launch plumbing of --gpus N, testable without a card")
@@ -304,6 +308,9 @@ def main():
         if shard_mode:
             lo = rank * N // world
             hi = (rank + 1) * N // world
+        elif args.rehearse_shard:
+            r_, R_ = (int(v) for v in args.rehearse_shard.split("/"))
+            lo, hi = r_ * N // R_, (r_ + 1) * N // R_
         else:
             lo, hi = 0, N
         n_local = hi - lo
@@ -358,7 +365,7 @@ def main():
                 q = q.to(torch.bfloat16).to(torch.float32)
             qsets.append(q.contiguous())
             ti, td = synth.brute_force_topk_native(x, q, k)  # exact truth: float32 MFMA brute force
-            truths.append((ti + lo, td))
+            truths.append((ti + (lo if shard_mode else 0), td))  # (a rehearsed shard answers in local ids)
         torch.cuda.synchronize()
 
         # one output set per search in flight
@@ -498,12 +505,13 @@ def main():
             "data": "synthetic",
             "recall_at_10": round(recall, 4),
             "config": {
-                "workload": f"{N} x {d} {args.row_dtype} rows resident in HBM (in-memory provider), "
+                "workload": f"{n_local if args.rehearse_shard else N} x {d} {args.row_dtype} rows resident in HBM (in-memory provider), "
                             + ("hierarchical Gaussian mixture" if args.dataset == "G" else
                                "dataset U: i.i.d. uniform [-1,1) rows (benches/hnsw_benchmarks.rs:9-14)") +
                             f", graph deg<= 60 (mean {gst['deg_mean']:.1f}), "
                             f"query batch {nq}, k={k}, ef={ef}, cosine",
                 "nodes": N, "dim": d, "query_batch": nq, "k": k, "ef": ef,
+                "rehearsed_shard": ({"shard": args.rehearse_shard, "rows": [lo, hi]} if args.rehearse_shard else None),
                 "parallelism": ("single" if world == 1 else
                                 (f"shard{world}: node-id ranges, RCCL all-gather + top-k merge"
                                  if shard_mode else f"replica{world}")),

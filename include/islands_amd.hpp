@@ -328,6 +328,63 @@ class Searcher {
   SearchConfig config_;
 };
 
+// ---- MultiIndexSearcher over id-range shards, one rank per GPU (search.rs:211-237) ------------
+// ShardGroup = the ranks' communicator: RCCL from a unique id rank 0 made (unique_id(), carried to the
+// other ranks by the host's own means), or a blocking host all-gather callback.
+class ShardGroup {
+ public:
+  static std::vector<uint8_t> unique_id() {
+    std::vector<uint8_t> id(ISL_SHARD_UNIQUE_ID_BYTES);
+    check(isl_shard_unique_id(id.data()));
+    return id;
+  }
+  ShardGroup(int32_t device, int32_t world, int32_t rank, const std::vector<uint8_t>& id) {
+    check(isl_shard_group_create(device, world, rank, id.data(), &h_));
+  }
+  ShardGroup(int32_t device, int32_t world, int32_t rank, isl_shard_allgather_fn fn, void* user) {
+    check(isl_shard_group_create_host(device, world, rank, fn, user, &h_));
+  }
+  ShardGroup(const ShardGroup&) = delete;
+  ShardGroup& operator=(const ShardGroup&) = delete;
+  ~ShardGroup() { isl_shard_group_free(h_); }
+  int32_t comm_ranks() const { int32_t n = 0; check(isl_shard_group_info(h_, nullptr, nullptr, &n, nullptr)); return n; }
+  isl_shard_group* handle() const { return h_; }
+
+ private:
+  isl_shard_group* h_ = nullptr;
+};
+
+struct ShardedResult { uint64_t id; float score; uint32_t shard; };
+
+class ShardedSearcher {
+ public:
+  // `shard`: this rank's index over its id range (local ids); group = nullptr: a single shard
+  ShardedSearcher(const LeannIndex& shard, ShardGroup* group, uint64_t n_total, int32_t depth = 8) {
+    check(isl_sharded_searcher_new(shard.handle(), group ? group->handle() : nullptr, n_total, nullptr, depth, &h_));
+  }
+  ShardedSearcher(const ShardedSearcher&) = delete;
+  ShardedSearcher& operator=(const ShardedSearcher&) = delete;
+  ~ShardedSearcher() { isl_sharded_searcher_free(h_); }
+  void prepare(uint64_t nq, uint64_t k, uint64_t ef) { check(isl_sharded_prepare(h_, nq, k, ef)); }
+  // the same batch on every rank; every rank gets the merged answer (global ids, ascending, ties -> lower shard)
+  std::vector<std::vector<ShardedResult>> search_batch(const std::vector<float>& queries, uint64_t nq, uint64_t k,
+                                                       uint64_t ef) {
+    std::vector<uint64_t> ids(nq * k);
+    std::vector<float> dist(nq * k);
+    std::vector<uint32_t> src(nq * k), cnt(nq);
+    check(isl_sharded_search_batch(h_, queries.data(), nq, queries.size() / nq, k, ef, ids.data(), dist.data(), src.data(),
+                                   cnt.data()));
+    std::vector<std::vector<ShardedResult>> out(nq);
+    for (uint64_t q = 0; q < nq; q++)
+      for (uint32_t j = 0; j < cnt[q]; j++) out[q].push_back({ids[q * k + j], dist[q * k + j], src[q * k + j]});
+    return out;
+  }
+  isl_sharded_searcher* handle() const { return h_; }
+
+ private:
+  isl_sharded_searcher* h_ = nullptr;
+};
+
 // ---- embedding/candle_provider.rs ---------------------------------------------------------
 // CandleEmbedder after tokenisation (candle_provider.rs:226-507): weights by checkpoint tensor
 // name, embed = embed_texts_raw on padded token ids.

@@ -119,6 +119,23 @@ static void test_gpu() {
     }
     EXPECT(isl_search_wait(idx.handle(), tok[0]) == ISL_ERR_INVALID_ARGUMENT);  // a token completes once
   }
+  // MultiIndexSearcher over id-range shards through the C++ mirror: the one rank this process is, with
+  // the RCCL transport (communicator from a unique id, all-gather of the packed record, merge) --
+  // the merged answer of a single shard is that shard's answer with global ids = local ids
+  {
+    ShardGroup grp(0, 1, 0, ShardGroup::unique_id());
+    EXPECT(grp.comm_ranks() == 1);
+    ShardedSearcher ss(idx, &grp, n, 2);
+    ss.prepare(4, 5, 200);
+    std::vector<float> qs(vecs.begin(), vecs.begin() + 3 * d);
+    auto merged = ss.search_batch(qs, 3, 5, 200);
+    for (size_t i = 0; i < 3; ++i) {
+      auto want = idx.search_with_params(std::vector<float>(vecs.begin() + i * d, vecs.begin() + (i + 1) * d), 5, 200);
+      EXPECT(merged[i].size() == want.size());
+      for (size_t j = 0; j < want.size() && j < merged[i].size(); ++j)
+        EXPECT(merged[i][j].id == want[j].first && merged[i][j].score == want[j].second && merged[i][j].shard == 0);
+    }
+  }
   LeannIndex empty = LeannIndex::with_defaults();  // :1306-1313
   EXPECT(empty.search(std::vector<float>(8, 0.5f), 5).empty());
 

@@ -184,7 +184,7 @@ def main():
         midx.set_pq_codes(pq, None, device_ptr=codes.data_ptr(), n=N)
         sweep = []
         for efv in sorted(set(efs + [128, 192, 256, 384])):
-            for a_ in (0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0):
+            for a_ in (0.05, 0.1, 0.15, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 1.0):
                 ids, dist, cnt = midx.search_two_level_batch(qh, args.k, efv, a_)
                 st = midx.last_stats()
                 sweep.append({"ef": efv, "ratio": a_, "recall_at_10": round(recall_of(ids, cnt), 4),
