@@ -7,6 +7,8 @@
 // column) l % 32 and the 8 consecutive k values 8 * (l / 32) .. + 7 of each 16-wide k step.
 #pragma once
 
+#include <type_traits>
+
 #include "common.hpp"
 #include "gemm_f32.hip.h"
 
@@ -373,6 +375,209 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_bf16_dma(const __bf16* _
         }
       }
   }
+}
+
+// ---- the 256 x 256 tile on the eight-phase schedule of the CDNA4 guide's GEMM template ----
+// (cdna_hip_programming.md, "The 256^2 8-phase template": the structure is the guide's, written out
+// here from its description.)  Same tile, wave decomposition (2 x 4 waves, 128 x 64 per wave),
+// 16x16x32 MFMAs, LDS image and accumulation order per output element as gemm_tn_bf16_dma<..,2,4,4,2>
+// above -- every output bit is the same -- but the K loop is cut differently:
+//   * a K-tile (64 deep) is FOUR half-tiles of 16 KiB: A0 / A1 = the rows of the first / second
+//     64-row half of every wave's 128 rows, B0 / B1 = the first / second 32 columns of every wave's 64;
+//     a wave's quadrant (ai, bj) of its output reads half-tiles A<ai> and B<bj> only;
+//   * four phases per K-tile, one quadrant each: (0,0) (0,1) (1,1) (1,0).  A phase = [fragment reads of
+//     what the quadrant still lacks: B0 + A0 | B1 | A1 | nothing] + [ONE half-tile of prefetch: 2 LDS-DMA
+//     instructions per wave] -> s_barrier -> lgkmcnt(0) -> 16 MFMAs -> s_barrier;
+//   * the prefetch runs three half-tiles ahead of the K-tile being waited for: phase 1 of K-tile s
+//     stages A1(s+1), phases 2, 3, 4 stage B0, A0, B1 of K-tile s+2 into the buffer being read -- each
+//     slot two phases after its last fragment read (B0: one phase, its reads are retired by the
+//     lgkmcnt(8) in front of phase 1's barrier) -- and the only vmcnt wait of a K-tile sits in phase 4,
+//     counted (6 = the three half-tiles staged since), never 0: nothing drains;
+//   * waves 4..7 run one barrier behind waves 0..3, so that on every SIMD one wave's MFMA section
+//     lies beside its partner's read / DMA section (matrix beside memory).
+// Round 2's stamps said the 8-wave kernel above loses a third of a slab's time to the DMA issue of
+// all pieces right behind the barrier; here a phase issues two.
+template <int ACT, bool RES, bool C16>
+__global__ __launch_bounds__(512) void gemm_tn_bf16_ph8(const __bf16* __restrict__ A, const __bf16* __restrict__ W,
+                                                        const float* __restrict__ bias, const float* __restrict__ R,
+                                                        void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K,
+                                                        uint32_t ntn, uint64_t ldc) {
+  constexpr uint32_t TM = 256, TN = 256, HT = 16384, KT = 4 * HT;  // half-tile, K-tile image [A0 | A1 | B0 | B1]
+  float* C = reinterpret_cast<float*>(Cv);
+  __bf16* Ch = reinterpret_cast<__bf16*>(Cv);
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // [2][KT]
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t nwg = gridDim.x, orig = blockIdx.x;
+  const uint32_t q8 = nwg / 8, r8 = nwg % 8, xcd = orig % 8;
+  const uint32_t wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + orig / 8;
+  const uint32_t ntm = nwg / ntn;
+  constexpr uint32_t GM = 8;
+  const uint32_t group = wgid / (GM * ntn), in_group = wgid % (GM * ntn);
+  const uint32_t gm = ntm - group * GM < GM ? ntm - group * GM : GM;
+  const uint64_t m0 = (uint64_t)(group * GM + in_group % gm) * TM, n0 = (uint64_t)(in_group / gm) * TN;
+  const uint32_t wr = wave >> 2, wc = wave & 3;
+  const uint32_t wm = wr * 128, wn = wc * 64;
+  typedef float floatx4_t __attribute__((ext_vector_type(4)));
+  floatx4_t acc4[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc4[i][j][r] = 0.0f;
+  // staging: piece q = 8 i + wave (i = 0, 1) of a half-tile image = its rows 8 q .. 8 q + 7 (1 KiB); LDS
+  // chunk `pos` of image row r holds the row's 16-byte chunk pos ^ ((r >> 1) & 7)
+  const __bf16* src[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t chunk = (8u * i + wave) * 64u + lane, r = chunk >> 3, c = (chunk & 7u) ^ ((r >> 1) & 7u);
+      if (t < 2) {  // A<t>: image row r = 64 wr' + x  <->  tile row 128 wr' + 64 t + x
+        const uint64_t row = m0 + (r >> 6) * 128u + t * 64u + (r & 63u);
+        src[t][i] = A + (row < M ? row : (uint64_t)M - 1) * K + c * 8u;
+      } else {      // B<t-2>: image row r = 32 wc' + x  <->  tile column 64 wc' + 32 (t - 2) + x
+        const uint64_t col = n0 + (r >> 5) * 64u + (t - 2) * 32u + (r & 31u);
+        src[t][i] = W + (col < N ? col : (uint64_t)N - 1) * K + c * 8u;
+      }
+    }
+  auto stage = [&](auto tt, uint32_t kt) {
+    constexpr int t = decltype(tt)::value;
+    unsigned char* dst = lds + (kt & 1u) * KT + t * HT + wave * 1024u;
+    __builtin_amdgcn_global_load_lds((isl_glb_void*)(src[t][0] + (uint64_t)kt * HBK), (isl_lds_void*)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((isl_glb_void*)(src[t][1] + (uint64_t)kt * HBK), (isl_lds_void*)(dst + 8192u), 16, 0, 0);
+  };
+  using T_A0 = std::integral_constant<int, 0>; using T_A1 = std::integral_constant<int, 1>;
+  using T_B0 = std::integral_constant<int, 2>; using T_B1 = std::integral_constant<int, 3>;
+  // fragment reads: lane group g = lane / 16 holds k = 8 g .. 8 g + 7 of a 32-deep step, c16 = its row in
+  // the 16-row block; (row >> 1) & 7 == c16 >> 1 for every block (block starts are multiples of 16)
+  const uint32_t g = lane >> 4, c16 = lane & 15, sw = c16 >> 1;
+  const uint32_t aoff0 = (wr * 64u + c16) * 128u + (((0u + g) ^ sw) << 4), aoff1 = (wr * 64u + c16) * 128u + (((4u + g) ^ sw) << 4);
+  const uint32_t boff0 = (wc * 32u + c16) * 128u + (((0u + g) ^ sw) << 4), boff1 = (wc * 32u + c16) * 128u + (((4u + g) ^ sw) << 4);
+  bf16x8 fa[4][2];      // the A half of the current quadrants: 4 row blocks x 2 k-steps
+  bf16x8 fb0[2][2], fb1[2][2];  // B0 and B1 stay in registers for the whole K-tile
+  auto read_a = [&](const unsigned char* img) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[i][0] = *reinterpret_cast<const bf16x8*>(img + aoff0 + i * 2048u);
+      fa[i][1] = *reinterpret_cast<const bf16x8*>(img + aoff1 + i * 2048u);
+    }
+  };
+  auto read_b = [&](bf16x8 (&fb)[2][2], const unsigned char* img) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      fb[j][0] = *reinterpret_cast<const bf16x8*>(img + boff0 + j * 2048u);
+      fb[j][1] = *reinterpret_cast<const bf16x8*>(img + boff1 + j * 2048u);
+    }
+  };
+  auto quadrant = [&](auto ai_, auto bj_, const bf16x8 (&fb)[2][2]) {
+    constexpr int ai = decltype(ai_)::value, bj = decltype(bj_)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s32 = 0; s32 < 2; ++s32)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc4[4 * ai + i][2 * bj + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][s32], fb[j][s32], acc4[4 * ai + i][2 * bj + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  auto barrier = [] {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto reads_done = [] {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const uint32_t nk = K / HBK;
+  // prologue: K-tile 0 whole, then the three half-tiles of K-tile 1 that phases 2-4 of "K-tile -1" would have staged
+  stage(T_A0{}, 0); stage(T_B0{}, 0); stage(T_B1{}, 0); stage(T_A1{}, 0);
+  if (nk > 1) {
+    stage(T_B0{}, 1); stage(T_A0{}, 1); stage(T_B1{}, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  barrier();               // every wave's pieces of K-tile 0 have landed
+  if (wr == 1) barrier();  // waves 4..7 run one barrier behind from here on
+  for (uint32_t s = 0; s < nk; ++s) {
+    const unsigned char* cur = lds + (s & 1u) * KT;
+    // phase 1: quadrant (0, 0)
+    read_b(fb0, cur + 2 * HT);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(cur);
+    if (s + 1 < nk) stage(T_A1{}, s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the four B0 reads are back: its slot is restaged next phase
+    barrier();
+    reads_done();
+    quadrant(I0{}, I0{}, fb0);
+    barrier();
+    // phase 2: quadrant (0, 1)
+    read_b(fb1, cur + 3 * HT);
+    if (s + 2 < nk) stage(T_B0{}, s + 2);
+    barrier();
+    reads_done();
+    quadrant(I0{}, I1{}, fb1);
+    barrier();
+    // phase 3: quadrant (1, 1)
+    read_a(cur + HT);
+    if (s + 2 < nk) stage(T_A0{}, s + 2);
+    barrier();
+    reads_done();
+    quadrant(I1{}, I1{}, fb1);
+    barrier();
+    // phase 4: quadrant (1, 0); the K-tile's one wait: everything but the last three half-tiles has landed
+    if (s + 2 < nk) {
+      stage(T_B1{}, s + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (s + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    barrier();
+    quadrant(I1{}, I0{}, fb0);
+    barrier();
+  }
+  if (wr == 0) barrier();  // (the barrier waves 4..7 took at the start)
+  auto emit = [&](uint64_t m, uint64_t n, float bv, float rm, float v) {
+    if (ACT <= 2) {
+      v += bv;
+      if (ACT == 1) v = gelu_erf_f(v);
+      if (ACT == 2) v = gelu_tanh_f(v);
+      if (RES) v += R[m * N + n];
+    } else if (ACT == EPI_COSINE) {
+      v = epi_cosine(v, rm, bv);
+    } else if (ACT == EPI_DOT) {
+      v = -v;
+    } else if (ACT == EPI_EUCLIDEAN) {
+      v = epi_euclidean(v, rm, bv);
+    }
+    if constexpr (C16) Ch[m * N + n] = (__bf16)v;
+    else C[(uint64_t)m * ldc + n] = v;
+  };
+  constexpr bool ROWNORM = ACT == EPI_COSINE || ACT == EPI_EUCLIDEAN;
+  float bvs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t n = n0 + wn + j * 16 + (lane & 15);
+    bvs[j] = (bias && n < N) ? bias[n] : 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint64_t m = m0 + wm + i * 16 + 4 * (lane >> 4) + r;
+      if (m >= M) continue;
+      const float rm = ROWNORM ? R[m] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint64_t n = n0 + wn + j * 16 + (lane & 15);
+        if (n < N) emit(m, n, bvs[j], rm, acc4[i][j][r]);
+      }
+    }
 }
 
 // Picks the tile by the size of the problem: the 256 x 256 tile needs enough tiles to fill the chip.

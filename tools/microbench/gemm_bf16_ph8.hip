@@ -1,0 +1,140 @@
+// The bf16 GEMM on the eight-phase schedule (gemm_tn_bf16_ph8) against the product's 8-wave LDS-DMA kernel
+// (gemm_tn_bf16_dma<..,2,4,4,2>) in ONE process on one card, rounds interleaved, plus a bit-for-bit
+// comparison of every output element (the two accumulate each element in the same order):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I islands_amd/csrc tools/microbench/gemm_bf16_ph8.hip -o tools/microbench/gemm_bf16_ph8
+//   tools/microbench/gemm_bf16_ph8 [M N K]
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "gemm_bf16.hip.h"
+using namespace isl_gemm;
+
+static const float* g_rn = nullptr;
+static const float* g_qn = nullptr;
+constexpr size_t kLds = 2 * (256 + 256) * HBK * 2;
+
+template <int EPI, bool PH8>
+static float run(const __bf16* A, const __bf16* W, float* C, uint32_t M, uint32_t N, uint32_t K, int reps) {
+  const uint32_t ntn = (N + 255) / 256, ntiles = ((M + 255) / 256) * ntn;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  auto launch = [&] {
+    if constexpr (PH8) {
+      auto kern = gemm_tn_bf16_ph8<EPI, false, false>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+      hipLaunchKernelGGL(kern, dim3(ntiles), dim3(512), kLds, 0, A, W, g_rn, g_qn, C, M, N, K, ntn, (uint64_t)N);
+    } else {
+      auto kern = gemm_tn_bf16_dma<EPI, false, false, 2, 4, 4, 2, 0>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+      hipLaunchKernelGGL(kern, dim3(ntiles), dim3(512), kLds, 0, A, W, g_rn, g_qn, C, M, N, K, ntn, (uint64_t)N, (uint64_t*)nullptr);
+    }
+  };
+  launch();
+  (void)hipEventRecord(e0);
+  for (int r = 0; r < reps; ++r) launch();
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms / reps;
+}
+
+__global__ void count_diff(const uint32_t* a, const uint32_t* b, uint64_t n, unsigned long long* out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long d = 0;
+  for (; i < n; i += (uint64_t)gridDim.x * blockDim.x) d += a[i] != b[i];
+  if (d) atomicAdd(out, d);
+}
+
+static unsigned long long differing(const float* a, const float* b, uint64_t n) {
+  unsigned long long* d;
+  (void)hipMalloc(&d, 8);
+  (void)hipMemset(d, 0, 8);
+  hipLaunchKernelGGL(count_diff, dim3(4096), dim3(256), 0, 0, (const uint32_t*)a, (const uint32_t*)b, n, d);
+  unsigned long long h = 0;
+  (void)hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  return h;
+}
+
+static void fill(std::vector<uint16_t>& h, uint32_t seed, float scale) {
+  uint32_t s = seed;
+  for (auto& v : h) {  // uniform in (-scale, scale), truncated to bf16
+    s = s * 1664525u + 1013904223u;
+    float f = (((s >> 8) & 0xFFFF) / 32768.0f - 1.0f) * scale;
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    v = (uint16_t)(u >> 16);
+  }
+}
+
+int main(int argc, char** argv) {
+  uint32_t M = argc > 3 ? atoi(argv[1]) : 4096, N = argc > 3 ? atoi(argv[2]) : 65536, K = argc > 3 ? atoi(argv[3]) : 4096;
+  const int reps = argc > 4 ? atoi(argv[4]) : 40;
+  // edge shapes first (ragged last tiles, one K-tile, two, an odd number): correctness only
+  {
+    const uint32_t shapes[][3] = {{300, 1000, 64}, {257, 513, 128}, {256, 256, 192}, {1000, 300, 448}, {512, 768, 4096}};
+    for (auto& sh : shapes) {
+      const uint32_t m = sh[0], n = sh[1], k = sh[2];
+      __bf16 *a, *w; float *c0, *c1, *rn, *qn;
+      (void)hipMalloc(&a, (size_t)m * k * 2); (void)hipMalloc(&w, (size_t)n * k * 2);
+      (void)hipMalloc(&c0, (size_t)m * n * 4); (void)hipMalloc(&c1, (size_t)m * n * 4);
+      (void)hipMalloc(&rn, (size_t)n * 4); (void)hipMalloc(&qn, (size_t)m * 4);
+      std::vector<uint16_t> ha((size_t)m * k), hw((size_t)n * k);
+      fill(ha, 7 + m, 1.0f); fill(hw, 11 + n, 1.0f);
+      (void)hipMemcpy(a, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
+      (void)hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+      std::vector<float> ones(n > m ? n : m, (float)k / 3.0f);
+      (void)hipMemcpy(rn, ones.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+      (void)hipMemcpy(qn, ones.data(), (size_t)m * 4, hipMemcpyHostToDevice);
+      g_rn = rn; g_qn = qn;
+      (void)hipMemset(c0, 0xFF, (size_t)m * n * 4); (void)hipMemset(c1, 0xFF, (size_t)m * n * 4);
+      (void)run<EPI_COSINE, false>(a, w, c0, m, n, k, 1);
+      (void)run<EPI_COSINE, true>(a, w, c1, m, n, k, 1);
+      const hipError_t e = hipDeviceSynchronize();
+      printf("shape %u x %u x %u: %llu differing elements (%s)\n", m, n, k, differing(c0, c1, (uint64_t)m * n), hipGetErrorString(e));
+      (void)hipFree(a); (void)hipFree(w); (void)hipFree(c0); (void)hipFree(c1); (void)hipFree(rn); (void)hipFree(qn);
+    }
+  }
+  __bf16 *A, *W; float *C0, *C1, *rn, *qn;
+  (void)hipMalloc(&A, (size_t)M * K * 2); (void)hipMalloc(&W, (size_t)N * K * 2);
+  (void)hipMalloc(&C0, (size_t)M * N * 4); (void)hipMalloc(&C1, (size_t)M * N * 4);
+  (void)hipMalloc(&rn, (size_t)N * 4); (void)hipMalloc(&qn, (size_t)M * 4);
+  {
+    std::vector<uint16_t> ha((size_t)M * K), hw((size_t)N * K);
+    fill(ha, 12345, 0.0156f * 1.7f);  // the scale of L2-normalised rows of d = 4096
+    fill(hw, 54321, 0.0156f * 1.7f);
+    (void)hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+    std::vector<float> ones(N > M ? N : M, 1.0f);
+    (void)hipMemcpy(rn, ones.data(), (size_t)N * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(qn, ones.data(), (size_t)M * 4, hipMemcpyHostToDevice);
+  }
+  g_rn = rn; g_qn = qn;
+  const double fl = 2.0 * M * N * K;
+  for (int round = 0; round < 4; ++round) {
+    const float t0 = run<EPI_DOT, false>(A, W, C0, M, N, K, reps);
+    const float t1 = run<EPI_DOT, true>(A, W, C1, M, N, K, reps);
+    const float t2 = run<EPI_COSINE, false>(A, W, C0, M, N, K, reps);
+    const float t3 = run<EPI_COSINE, true>(A, W, C1, M, N, K, reps);
+    printf("M=%u N=%u K=%u round %d: dot epilogue: 8-wave DMA %.3f ms %.1f TF | 8-phase %.3f ms %.1f TF || cosine: %.3f ms %.1f TF | %.3f ms %.1f TF\n",
+           M, N, K, round, t0, fl / t0 / 1e9, t1, fl / t1 / 1e9, t2, fl / t2 / 1e9, t3, fl / t3 / 1e9);
+    fflush(stdout);
+  }
+  printf("cosine outputs, differing elements of %llu: %llu\n", (unsigned long long)M * N, differing(C0, C1, (uint64_t)M * N));
+  (void)run<EPI_DOT, false>(A, W, C0, M, N, K, 1);
+  (void)run<EPI_DOT, true>(A, W, C1, M, N, K, 1);
+  printf("dot outputs, differing elements: %llu\n", differing(C0, C1, (uint64_t)M * N));
+  // a race screen: the 8-phase kernel twenty more times against the first result
+  unsigned long long bad = 0;
+  for (int it = 0; it < 20; ++it) {
+    (void)run<EPI_DOT, true>(A, W, C1, M, N, K, 1);
+    bad += differing(C0, C1, (uint64_t)M * N);
+  }
+  printf("race screen, 20 further runs of the 8-phase kernel: %llu differing elements in all\n", bad);
+  return 0;
+}
