@@ -397,7 +397,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_bf16_dma(const __bf16* _
 //     lies beside its partner's read / DMA section (matrix beside memory).
 // Round 2's stamps said the 8-wave kernel above loses a third of a slab's time to the DMA issue of
 // all pieces right behind the barrier; here a phase issues two.
-template <int ACT, bool RES, bool C16>
+// VAR (tools/microbench/gemm_bf16_ph8.hip only): bit 0 = no s_setprio around the MFMA clusters; bit 1 = one
+// static s_setprio 1 for waves 4..7 instead.
+template <int ACT, bool RES, bool C16, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm_tn_bf16_ph8(const __bf16* __restrict__ A, const __bf16* __restrict__ W,
                                                         const float* __restrict__ bias, const float* __restrict__ R,
                                                         void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K,
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_ph8(const __bf16* __restrict
   };
   auto quadrant = [&](auto ai_, auto bj_, const bf16x8 (&fb)[2][2]) {
     constexpr int ai = decltype(ai_)::value, bj = decltype(bj_)::value;
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (!(VAR & 1)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s32 = 0; s32 < 2; ++s32)
 #pragma unroll
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_ph8(const __bf16* __restrict
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc4[4 * ai + i][2 * bj + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][s32], fb[j][s32], acc4[4 * ai + i][2 * bj + j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (!(VAR & 1)) __builtin_amdgcn_s_setprio(0);
   };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   auto barrier = [] {
@@ -503,6 +505,9 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_ph8(const __bf16* __restrict
   }
   barrier();               // every wave's pieces of K-tile 0 have landed
   if (wr == 1) barrier();  // waves 4..7 run one barrier behind from here on
+  if constexpr ((VAR & 2) != 0) {
+    if (__builtin_amdgcn_readfirstlane(wr) == 1) __builtin_amdgcn_s_setprio(1);
+  }
   for (uint32_t s = 0; s < nk; ++s) {
     const unsigned char* cur = lds + (s & 1u) * KT;
     // phase 1: quadrant (0, 0)
@@ -587,7 +592,20 @@ void launch_gemm_bf16_dma(const __bf16* A, const __bf16* W, const float* bias, c
   static const int tile_env = [] { const char* e = getenv("ISL_GEMM_TILE"); return e ? atoi(e) : 0; }();  // 128 / 256: A/B switch
   const uint64_t big = ((M + 255) / 256) * ((N + 255) / 256);
   const bool use_big = tile_env == 256 || (tile_env != 128 && big >= 512);
-  if (use_big) {
+  // the 256 x 256 tile runs on the eight-phase schedule (gemm_tn_bf16_ph8: same outputs bit for bit, 4-5 %
+  // faster on 4096 x 65536 x 4096, tools/microbench/gemm_bf16_ph8.hip); ISL_GEMM_PH8=0 keeps round 2's loop
+  static const bool ph8 = [] { const char* e = getenv("ISL_GEMM_PH8"); return !e || atoi(e) != 0; }();
+  if (use_big && ph8) {
+    auto kern = gemm_tn_bf16_ph8<ACT, RES, C16>;
+    constexpr size_t lds = 2 * (256 + 256) * HBK * 2;
+    static const bool once = [&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL(kern, dim3((uint32_t)big), dim3(512), lds, st, A, W, bias, R, C, (uint32_t)M, (uint32_t)N,
+                       (uint32_t)K, (uint32_t)((N + 255) / 256), ldc);
+  } else if (use_big) {
     auto kern = gemm_tn_bf16_dma<ACT, RES, C16, 2, 4, 4, 2>;
     constexpr size_t lds = 2 * (256 + 256) * HBK * 2;
     static const bool once = [&] {

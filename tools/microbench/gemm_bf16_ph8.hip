@@ -16,7 +16,7 @@ static const float* g_rn = nullptr;
 static const float* g_qn = nullptr;
 constexpr size_t kLds = 2 * (256 + 256) * HBK * 2;
 
-template <int EPI, bool PH8>
+template <int EPI, bool PH8, int VAR = 0>
 static float run(const __bf16* A, const __bf16* W, float* C, uint32_t M, uint32_t N, uint32_t K, int reps) {
   const uint32_t ntn = (N + 255) / 256, ntiles = ((M + 255) / 256) * ntn;
   hipEvent_t e0, e1;
@@ -24,7 +24,7 @@ static float run(const __bf16* A, const __bf16* W, float* C, uint32_t M, uint32_
   (void)hipEventCreate(&e1);
   auto launch = [&] {
     if constexpr (PH8) {
-      auto kern = gemm_tn_bf16_ph8<EPI, false, false>;
+      auto kern = gemm_tn_bf16_ph8<EPI, false, false, VAR>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
       hipLaunchKernelGGL(kern, dim3(ntiles), dim3(512), kLds, 0, A, W, g_rn, g_qn, C, M, N, K, ntn, (uint64_t)N);
     } else {
@@ -119,10 +119,12 @@ int main(int argc, char** argv) {
   for (int round = 0; round < 4; ++round) {
     const float t0 = run<EPI_DOT, false>(A, W, C0, M, N, K, reps);
     const float t1 = run<EPI_DOT, true>(A, W, C1, M, N, K, reps);
+    const float v1 = run<EPI_DOT, true, 1>(A, W, C1, M, N, K, reps), v3 = run<EPI_DOT, true, 3>(A, W, C1, M, N, K, reps);
     const float t2 = run<EPI_COSINE, false>(A, W, C0, M, N, K, reps);
     const float t3 = run<EPI_COSINE, true>(A, W, C1, M, N, K, reps);
     printf("M=%u N=%u K=%u round %d: dot epilogue: 8-wave DMA %.3f ms %.1f TF | 8-phase %.3f ms %.1f TF || cosine: %.3f ms %.1f TF | %.3f ms %.1f TF\n",
            M, N, K, round, t0, fl / t0 / 1e9, t1, fl / t1 / 1e9, t2, fl / t2 / 1e9, t3, fl / t3 / 1e9);
+    printf("   8-phase, dot: no setprio %.1f TF | static priority for waves 4..7 only %.1f TF\n", fl / v1 / 1e9, fl / v3 / 1e9);
     fflush(stdout);
   }
   printf("cosine outputs, differing elements of %llu: %llu\n", (unsigned long long)M * N, differing(C0, C1, (uint64_t)M * N));
