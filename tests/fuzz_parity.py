@@ -279,6 +279,31 @@ def recompute_case(rng, case):
         assert bits(got[1]).tolist() == bits(want[1]).tolist(), desc
         for f in ("expansions", "edges", "evals", "pushes"):
             assert st[f] == ws[f], (desc, f, st[f], ws[f])
+    # the two-level search over the same pair of providers (round 3: it parks and resumes too, any
+    # cache size; a ratio of 1 with a small ef takes the window retry inside the recompute rounds)
+    if rng.random() < 0.6 and ef <= 512:
+        from test_two_level_cpu import make_pq
+        m = int(rng.choice([2, 4, 8, 16]))
+        K = int(rng.choice([8, 32, 64]))
+        cb, codes = make_pq(emb, m, K, seed % 1000)
+        pq = ia.ProductQuantizer(emb.shape[1], cb, ia.DistanceMetric.Euclidean)
+        mem.set_pq_codes(pq, codes)
+        rec.set_pq_codes(pq, codes)
+        ratio = float(rng.choice([0.05, 0.2, 0.5, 1.0]))
+        rows2 = int(rng.choice([256, max(256, n // 3), n]))
+        rec.set_recompute_provider(enc, tok, lens, keep_rows=keep, cache_rows=rows2)
+        rec.set_pq_codes(pq, codes)
+        want2 = mem.search_two_level_batch(q, k, ef, ratio)
+        ws2 = mem.last_stats()
+        got2 = rec.search_two_level_batch(q, k, ef, ratio)
+        st2 = rec.last_stats()
+        d2 = desc + f" | two-level m={m} K={K} ratio={ratio} rows={rows2}"
+        assert got2[2].tolist() == want2[2].tolist(), d2
+        assert got2[0].tolist() == want2[0].tolist(), d2
+        assert bits(got2[1]).tolist() == bits(want2[1]).tolist(), d2
+        for f in ("expansions", "edges", "evals", "pushes"):
+            assert st2[f] == ws2[f], (d2, f, st2[f], ws2[f])
+        del pq
     return {"exact_path": ws["exact_path"], "replayed": ws["replayed"]}
 
 
