@@ -346,7 +346,10 @@ def main():
         # One stream per search in flight: 16 (all lanes) is the best measured on one GPU; past ~20 streams
         # on a card the runtime's 32 hardware queues run out and the rate collapses (24 lanes: 0.39 M q/s),
         # so ranks that also run the exchange's side stream and RCCL's own keep a margin.
-        depth = max(1, min(args.pipeline if args.pipeline > 0 else (16 if world == 1 else 12), 32))
+        # (a batch of fewer than 1024 queries fills a fraction of the chip's wave slots: more of them in
+        # flight, up to the 32 lanes -- config 2's 256-query batches)
+        auto_depth = (16 if nq >= 1024 else min(32, -(-16 * 1024 // max(nq, 1)))) if world == 1 else 12
+        depth = max(1, min(args.pipeline if args.pipeline > 0 else auto_depth, 32))
         idx.prepare(nq, ef, k, depth)
         torch.cuda.synchronize()
         log(f"index resident and {depth} search lanes prepared in {time.time() - t0:.1f}s")

@@ -49,14 +49,15 @@ def point(name, m, ef, a, call):
     print(json.dumps(r), flush=True)
 
 
-for ef in (128, 192, 256):
+EFS = tuple(int(e) for e in os.environ.get("SWEEP_EFS", "128,192,256,384,512").split(","))
+for ef in EFS[:3]:
     point("plain", 0, ef, None, lambda: idx.search_batch_device(q.data_ptr(), nq, d, k, ef, oi.data_ptr(), od.data_ptr(),
                                                                 oc.data_ptr()))
 for m in ms:
     cb, codes = synth.train_pq(x, m)
     pq = ia.ProductQuantizer(d, cb.cpu().numpy())
     idx.set_pq_codes(pq, None, device_ptr=codes.data_ptr(), n=N)
-    for ef in (128, 192, 256, 384, 512):
+    for ef in EFS:
         for a in (0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 1.0):
             try:
                 point("two-level", m, ef, a,
