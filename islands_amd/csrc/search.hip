@@ -696,7 +696,8 @@ isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws, uint32_
   ws.enqueued = false;
   const uint64_t nq = ws.nq_inflight;
   const bool use_fast = ws.fast_inflight;
-  if (ws.ev_done) ISL_HIP(hipEventSynchronize(ws.ev_done));
+  static const bool sync_stream = getenv("ISL_SYNC_STREAM") != nullptr;  // A/B switch for measurements
+  if (ws.ev_done && !sync_stream) ISL_HIP(hipEventSynchronize(ws.ev_done));
   else ISL_HIP(hipStreamSynchronize(ws.st_inflight));
   const uint32_t* status = ws.h_status;
   const uint32_t* ctr = ws.h_ctr;

@@ -12,6 +12,7 @@ float32 copy): the harness of tools/synth.py builds the graph on the bf16 rows, 
 the exact top-k under the library's own bf16 distance GEMM."""
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -174,6 +175,8 @@ def main():
 
     pipelined(0, a.warmup, plain(ef))
     torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()  # (a full collection of the interpreter takes tens of milliseconds with torch imported)
     t0 = time.perf_counter()
     agg, rec = pipelined(a.warmup, a.steps, plain(ef))
     torch.cuda.synchronize()
