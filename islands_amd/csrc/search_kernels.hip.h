@@ -1582,19 +1582,19 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
                 j += 64u;
                 while (j >= m) { j -= m; n += 1u; }
               }
+              // (pairs past the chunk's end load pair (0, 0) again: an `if` around a load makes the compiler
+              // branch and wait per element -- 32 dependent round trips instead of 2)
 #pragma unroll
               for (uint32_t i = 0; i < kTlPairs; ++i) {
-                const uint32_t t = lane + 64u * i;
-                code[i] = 0u;
-                if (t < total) code[i] = p.tl_codes[(uint64_t)scratch[n0 + cn[i]] * m + cj[i]];
+                const bool ok = lane + 64u * i < total;
+                cn[i] = ok ? cn[i] : 0u;
+                cj[i] = ok ? cj[i] : 0u;
               }
+#pragma unroll
+              for (uint32_t i = 0; i < kTlPairs; ++i) code[i] = p.tl_codes[(uint64_t)scratch[n0 + cn[i]] * m + cj[i]];
               float tv[kTlPairs];
 #pragma unroll
-              for (uint32_t i = 0; i < kTlPairs; ++i) {
-                const uint32_t t = lane + 64u * i;
-                tv[i] = 0.0f;
-                if (t < total) tv[i] = tables[(uint64_t)cj[i] * K + code[i]];
-              }
+              for (uint32_t i = 0; i < kTlPairs; ++i) tv[i] = tables[(uint64_t)cj[i] * K + code[i]];
 #pragma unroll
               for (uint32_t i = 0; i < kTlPairs; ++i) {
                 const uint32_t t = lane + 64u * i;
@@ -1602,8 +1602,18 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
               }
               wave_sync();
               if (lane >= n0 && lane < n0 + cnt) {
+                // sixteen entries read together, then added in order: one LDS latency per sixteen additions
+                // (an entry read and waited for per addition made the fold the longest part of the hop)
                 const float* row = tlv + (lane - n0) * (m + 1u);
-                for (uint32_t jj = 0; jj < m; ++jj) s += row[jj];
+                uint32_t jj = 0;
+                for (; jj + 16u <= m; jj += 16u) {
+                  float v[16];
+#pragma unroll
+                  for (int e = 0; e < 16; ++e) v[e] = row[jj + e];
+#pragma unroll
+                  for (int e = 0; e < 16; ++e) s += v[e];
+                }
+                for (; jj < m; ++jj) s += row[jj];
               }
               wave_sync();
             }
