@@ -155,3 +155,18 @@ def test_single_rank_rccl_group_and_host_entry():
     with pytest.raises(ia.CoreError):
         s.result(12345)
     s.close()
+
+
+def test_empty_shard_answers_with_zero_counts():
+    """A shard that holds no nodes (LeannIndex::search on an empty index is Ok(vec![]), leann.rs:875-877) still
+    takes part in the exchange: its record carries zero counts and the merge returns what the others found --
+    here, with one rank, nothing."""
+    import islands_amd as ia
+    from islands_amd.sharded import ShardedSearcher
+
+    idx = ia.LeannIndex.with_defaults().upload(0)
+    s = ShardedSearcher(0, index=idx, device="cuda:0", depth=2)
+    q = np.zeros((5, 16), np.float32)
+    ids, dd, src, cnt = s.search_batch(q, 3, 8)
+    assert cnt.tolist() == [0] * 5
+    s.close()

@@ -374,4 +374,20 @@ def test_recompute_index_on_the_async_entry_points(orc):
     st = rec_idx.wait_stats(t)
     assert st["recompute_rounds"] > 2 and st["encoded_nodes"] > 0
     assert o[0].cpu().numpy().astype(np.uint64).tolist() == want1[0].tolist()
+    # isl_search_stream_wait on such a token waits for the worker on the host; the answers are then there
+    # for work enqueued on the stream afterwards, and the token still completes once
+    import ctypes as C
+    from islands_amd import _check, _ffi
+    o[0].zero_()
+    t = rec_idx.search_batch_device_async(dq.data_ptr(), q1.shape[0], emb.shape[1], 10, 64, o[0].data_ptr(),
+                                          o[1].data_ptr(), o[2].data_ptr())
+    side = torch.cuda.Stream()
+    _check(_ffi.lib().isl_search_stream_wait(rec_idx._h, t, C.c_void_p(side.cuda_stream)))
+    with torch.cuda.stream(side):
+        copy = o[0].clone()
+    side.synchronize()
+    assert copy.cpu().numpy().astype(np.uint64).tolist() == want1[0].tolist()
+    rec_idx.wait(t)
+    with pytest.raises(ia.CoreError):
+        rec_idx.wait(t)
     del pq
