@@ -449,14 +449,16 @@ def main():
             return agg, kept
 
         trace = None
+        # The interpreter's cyclic garbage collector stays out of the timed regions: with torch imported a
+        # full collection takes 35-45 ms -- measured as ONE 37-45 ms call among 600 pipelined host-buffer calls
+        # (the 188th; none after), which is half of a 64-step timed region at query batch 256.  Collected
+        # BEFORE the warm-up: 40 ms of host work between warm-up and timed region would let the chip drop
+        # its clocks (measured: 6 % on the 20-step run).
+        gc.collect()
+        gc.disable()
         run(0, args.warmup, False)
         barrier()
         trace = [] if os.environ.get("ISL_BENCH_TRACE") else None  # completion times of the timed steps -> stderr
-        # The interpreter's cyclic garbage collector stays out of the timed regions: with torch imported a
-        # full collection takes 35-45 ms -- measured as ONE 37-45 ms call among 600 pipelined host-buffer calls
-        # (the 188th; none after), which is half of a 64-step timed region at query batch 256.
-        gc.collect()
-        gc.disable()
         t0 = time.perf_counter()
         agg, recalls = run(args.warmup, args.steps, True)
         barrier()
@@ -570,10 +572,10 @@ def main():
                     allocs += idx.wait_stats(pend.pop(0))["allocations"]
                 return allocs
 
-            host_run(0, min(args.warmup, 2))
-            torch.cuda.synchronize()
             gc.collect()
             gc.disable()
+            host_run(0, min(args.warmup, 2))
+            torch.cuda.synchronize()
             t1 = time.perf_counter()
             hall = host_run(0, args.steps)
             torch.cuda.synchronize()

@@ -173,10 +173,10 @@ def main():
         return lambda q_, o: idx.search_batch_device_async(q_.data_ptr(), nq, d, k, efv, o[0].data_ptr(), o[1].data_ptr(),
                                                            o[2].data_ptr())
 
-    pipelined(0, a.warmup, plain(ef))
-    torch.cuda.synchronize()
     gc.collect()
     gc.disable()  # (a full collection of the interpreter takes tens of milliseconds with torch imported)
+    pipelined(0, a.warmup, plain(ef))
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     agg, rec = pipelined(a.warmup, a.steps, plain(ef))
     torch.cuda.synchronize()
