@@ -179,7 +179,8 @@ isl_status ensure_lane_stream(const isl_index* idx, isl::SearchWorkspace& ws) {
   hipStream_t st = pool_stream(idx->device, (uint32_t)(&ws - idx->ws), &created);
   if (!st) return isl::fail(ISL_ERR_DEVICE, "hipStreamCreate failed for a search lane");
   if (created) ws.alloc_events++;
-  if (!ws.ev_done) { ISL_HIP(hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming)); ws.alloc_events++; }
+  static const bool no_evdone = getenv("ISL_NO_EVDONE") != nullptr;  // A/B switch for measurements (stream synchronisation instead)
+  if (!ws.ev_done && !no_evdone) { ISL_HIP(hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming)); ws.alloc_events++; }
   if (!ws.ev0) { ISL_HIP(hipEventCreate(&ws.ev0)); ws.alloc_events++; }
   if (!ws.ev1) { ISL_HIP(hipEventCreate(&ws.ev1)); ws.alloc_events++; }
   if (!ws.ev_in) { ISL_HIP(hipEventCreateWithFlags(&ws.ev_in, hipEventDisableTiming)); ws.alloc_events++; }
