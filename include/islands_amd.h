@@ -361,6 +361,7 @@ isl_status isl_shard_group_create_host(int32_t device, int32_t world, int32_t ra
  * host transport reports `world`); *is_rccl = 1 for the RCCL transport. */
 isl_status isl_shard_group_info(const isl_shard_group* grp, int32_t* world, int32_t* rank, int32_t* comm_ranks,
                                 int32_t* is_rccl);
+/* (a group must outlive the searchers created over it) */
 void isl_shard_group_free(isl_shard_group* grp);
 
 /* The searcher of one rank: `shard` is this rank's LeannIndex over its id range (resident, provider

@@ -1210,7 +1210,13 @@ void start_worker(const isl_index* idx, isl::SearchWorkspace* ws, F body) {
   ws->threaded = true;
   ws->worker = new std::thread([idx, ws, body]() {
     isl_status st = isl::use_device(idx->device);
-    if (st == ISL_OK) st = body();
+    try {  // nothing may leave the thread: an exception here would end the process
+      if (st == ISL_OK) st = body();
+    } catch (const std::exception& e) {
+      st = isl::fail(ISL_ERR_SEARCH, "Search error: %s", e.what());
+    } catch (...) {
+      st = isl::fail(ISL_ERR_SEARCH, "Search error: unknown exception in the call's worker thread");
+    }
     ws->worker_status = st;
     ws->worker_error = isl::last_error();
   });
