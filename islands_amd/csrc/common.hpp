@@ -117,6 +117,10 @@ struct SearchWorkspace {
   uint32_t* h_qlist = nullptr;   // [qlist_cap] pinned
   uint32_t* uslots = nullptr;    // [miss_cap] slab slots of the round's unique misses
   uint64_t qlist_cap = 0;
+  uint32_t* xslot = nullptr;     // [qlist_cap] 1 + pool slot of a query parked in the heap-exact kernel
+  uint32_t* h_xlist = nullptr;   // [64] pinned: the parked queries the next round hands to that kernel directly
+  uint32_t round_x = 0;          // ... how many
+  bool round_xpark = false;      // this call's queries park in the heap-exact kernel (bounded row cache)
   // the round search_sync is about to enqueue (recompute provider): 0 = an ordinary launch over
   // all queries; otherwise the RESUME kernel over `round_active` queries, listed in qlist unless
   // it is the first round
@@ -156,7 +160,9 @@ struct ExactPool {
   uint64_t vis_words = 0;
   uint32_t* ulist = nullptr;    // [slots][ulist_cap] unvisited ids of one hop
   uint32_t ulist_cap = 0;
-  uint32_t* locks = nullptr;    // [slots] 0 = free, 1 = held by a workgroup
+  uint32_t* locks = nullptr;    // [slots] 0 = free, 1 = held by a workgroup (or by a query parked in the slot)
+  uint32_t* xstate = nullptr;   // [slots][xstate_words] recompute provider: result heap + scalars of a parked query
+  uint32_t xstate_words = 0;
 };
 
 }  // namespace isl

@@ -104,6 +104,13 @@ __global__ void copy_u32_kernel(const uint32_t* __restrict__ src, uint32_t* __re
     dst[i] = src[i];
 }
 
+// recompute provider: the queries parked in the heap-exact kernel go straight back to its queue
+__global__ void seed_redo_kernel(const uint32_t* __restrict__ list, uint32_t n, uint32_t* __restrict__ redo,
+                                 uint32_t* __restrict__ ticket) {
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) redo[i] = list[i];
+  if (threadIdx.x == 0) ticket[1] = n;
+}
+
 constexpr uint32_t kExactSlots = 32;
 constexpr uint32_t kOvfBits = 15;
 constexpr uint32_t kMaxExactEf = 4096;
@@ -303,7 +310,9 @@ isl_status ensure_pool(const isl_index* idx, isl::SearchWorkspace& ws) {
       (st = lane_malloc(ws, pl.cand_id, (size_t)kExactSlots * pl.cand_cap * 4)) == ISL_OK &&
       (st = lane_malloc(ws, pl.vis_bits, (size_t)kExactSlots * pl.vis_words * 4)) == ISL_OK &&
       (st = lane_malloc(ws, pl.ulist, (size_t)kExactSlots * pl.ulist_cap * 4)) == ISL_OK &&
-      (st = lane_malloc(ws, pl.locks, (size_t)kExactSlots * 4)) == ISL_OK) {
+      (st = lane_malloc(ws, pl.locks, (size_t)kExactSlots * 4)) == ISL_OK &&
+      (st = lane_malloc(ws, pl.xstate, (size_t)kExactSlots * (16 + 2 * (kMaxExactEf + 1)) * 4)) == ISL_OK) {
+    pl.xstate_words = 16 + 2 * (kMaxExactEf + 1);
     if (hipMemset(pl.locks, 0, (size_t)kExactSlots * 4) == hipSuccess) {
       pl.slots = kExactSlots;
       return ISL_OK;
@@ -430,7 +439,7 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
   const uint32_t slots = cg.slots, plog_cap = cg.plog_cap;
   // searches over the recompute provider park and resume on the fast kernel (f32 rows; the
   // two-level and heap-exact kernels re-run a blocked query from its start instead)
-  const bool resume = !warm && ws.round_active != 0 && (tl || use_fast);
+  const bool resume = !warm && (ws.round_active != 0 || ws.round_x != 0);
   // two-level search over bf16 rows: first the instantiation that keeps a bf16-valued query as bf16
   // in LDS, then the float32-query one over the queries it passed on (not in a retry's list mode)
   static const bool no_tl_qh = getenv("ISL_NO_TL_QH") != nullptr;  // A/B switch for measurements
@@ -516,6 +525,11 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
   p.ulist_cap = idx->pool.ulist_cap;
   p.pool_locks = idx->pool.locks;
   p.pool_slots = idx->pool.slots;
+  if (resume && !tl && ws.round_xpark) {  // the heap-exact kernel parks and resumes too (recompute provider, bounded cache)
+    p.xslot = ws.xslot;
+    p.xstate = idx->pool.xstate;
+    p.xstate_words = idx->pool.xstate_words;
+  }
   p.slot_of = idx->recompute ? idx->d_slot_of : nullptr;
   p.stamp = idx->d_stamp;
   p.round_no = idx->round_no;
@@ -557,6 +571,10 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
   if (!ws.ticket_clean) ISL_HIP(hipMemsetAsync(ws.ticket, 0, 64, st));
   ws.ticket_clean = false;
   ISL_HIP(hipEventRecord(ws.ev0, st));
+  if (resume && !tl && ws.round_x) {
+    hipLaunchKernelGGL(seed_redo_kernel, dim3(1), dim3(256), 0, st, ws.h_xlist, ws.round_x, ws.redo, ws.ticket);
+    ISL_HIP(hipGetLastError());
+  }
   if (tl) {
     // build_distance_tables for the whole batch (pq.rs:307-338; once per call: the rounds of the
     // recompute provider and a retry keep them), then one wave per query
@@ -600,6 +618,7 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
   } else if (use_fast) {
     if (resume) p.nq = ws.round_active;  // the fast kernel runs this round's queries; nothing else reads nq
     uint32_t grid = (uint32_t)std::min<uint64_t>(resume ? ws.round_active : nq_grid, slots);
+    const bool skip_fast = resume && ws.round_active == 0;  // only queries parked in the heap-exact kernel this round
     int S = ef <= 64 ? 1 : ef <= 128 ? 2 : ef <= 256 ? 4 : 8;
     const int metric = (int)idx->cfg.metric;
     const bool wide = idx->max_degree > 64;
@@ -622,12 +641,12 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
       p.qsel_mode = 1;  // the others
       launch_fast(false, grid, fg.lds);
       p.qsel_mode = 0;
-    } else {
+    } else if (!skip_fast) {
       launch_fast(false, grid, fg.lds);
     }
     ISL_HIP(hipGetLastError());
     p.nq = (uint32_t)nq;
-  } else if (!warm) {
+  } else if (!warm && !resume) {
     // every query goes to the exact kernel: redo = [0, nq)
     std::vector<uint32_t> all(nq);
     for (uint64_t i = 0; i < nq; i++) all[i] = (uint32_t)i;
@@ -871,16 +890,20 @@ __global__ __launch_bounds__(64) void row_norm2_list_kernel(const float* __restr
 
 // query lists of a lane (rounds of the recompute provider, retries of the two-level search)
 isl_status ensure_qlist(isl::SearchWorkspace& ws, uint64_t nq) {
-  if (ws.qlist_cap >= nq && ws.qlist && ws.h_qlist && ws.qflag) return ISL_OK;
+  if (ws.qlist_cap >= nq && ws.qlist && ws.h_qlist && ws.qflag && ws.xslot && ws.h_xlist) return ISL_OK;
   if (ws.qflag) (void)hipFree(ws.qflag);
   if (ws.qlist) (void)hipFree(ws.qlist);
+  if (ws.xslot) (void)hipFree(ws.xslot);
   if (ws.h_qlist) (void)hipHostFree(ws.h_qlist);
-  ws.qflag = ws.qlist = ws.h_qlist = nullptr;
+  if (ws.h_xlist) (void)hipHostFree(ws.h_xlist);
+  ws.qflag = ws.qlist = ws.xslot = ws.h_qlist = ws.h_xlist = nullptr;
   ws.qlist_cap = 0;
   const uint64_t c = nq < 1024 ? 1024 : nq;
   ISL_TRY(lane_malloc(ws, ws.qflag, c * 4));
   ISL_TRY(lane_malloc(ws, ws.qlist, c * 4));
+  ISL_TRY(lane_malloc(ws, ws.xslot, c * 4));
   ISL_TRY(lane_host_malloc(ws, ws.h_qlist, c * 4));
+  ISL_TRY(lane_host_malloc(ws, ws.h_xlist, c * 4));
   ws.qlist_cap = c;
   return ISL_OK;
 }
@@ -968,9 +991,17 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
   const int S0 = cg0.ef <= 64 ? 1 : cg0.ef <= 128 ? 2 : cg0.ef <= 256 ? 4 : 8;
   // searches that park and resume: the wave-per-query traversal and the two-level search (the
   // heap-exact kernel alone -- ef > 512, rows past 128 ids -- re-runs a blocked query from its start)
-  const bool resumable = tl || cg0.use_fast;
+  // searches park and resume: the wave-per-query traversal, the two-level search, and -- since round 3 --
+  // the heap-exact kernel (ef > 512, rows past 128 ids, tie hand-overs), whose parked queries keep their
+  // slot of the scratch pool across the rounds
+  // -- when the row cache is bounded.  With a row for every node nothing is ever evicted, a blocked query
+  // of that kernel simply starts over next round (all of them advance in parallel, where parked ones
+  // would advance 32 at a time: the pool's slots).
+  const bool exact_only = !tl && !cg0.use_fast;
+  const bool x_park = !tl && idx->slab_rows < idx->nvec;
+  const bool resumable = tl || cg0.use_fast || x_park;
   ISL_TRY(prepare_recompute(ws, nq, tl ? isl_launch::tl_state_words(cg0.ef, cg0.tl_wcap, cg0.fg.hbits)
-                                       : resumable ? isl_launch::fast_state_words(S0, cg0.fg.hbits) : 1));
+                                       : cg0.use_fast ? isl_launch::fast_state_words(S0, cg0.fg.hbits) : 1));
   ISL_TRY(ensure_lane_stream(idx, ws));
   hipStream_t st = mode == StreamMode::USER ? user_stream : ws.stream;
   if (!idx->keep_rows) {  // every call starts from an empty cache: each node is encoded once per call
@@ -980,6 +1011,15 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
     ISL_HIP(hipMemsetAsync(idx->d_slab_head, 0, 8, st));
   }
   ISL_HIP(hipMemsetAsync(ws.qflag, 0, nq * 4, st));
+  ISL_HIP(hipMemsetAsync(ws.xslot, 0, nq * 4, st));
+  if (!tl) {
+    // no query is parked in the heap-exact kernel's pool yet (recompute calls run one at a time per index)
+    if (!idx->pool.slots) {
+      std::lock_guard<std::mutex> lock(idx->mu);
+      ISL_TRY(ensure_pool(idx, ws));
+    }
+    ISL_HIP(hipMemsetAsync(idx->pool.locks, 0, (size_t)idx->pool.slots * 4, st));
+  }
   uint64_t encoded = 0, rounds = 0;
   double kernel_ms = 0.0;
   // Queries in flight at a time: each may hold one hop (<= 128 rows) waiting for its last rows, and
@@ -987,19 +1027,41 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
   // every round serves every miss and every query in flight advances by a hop per round.  (2^20
   // rows: 4096 queries; a smaller cache works through the batch a few queries at a time.)
   // (A slab with a row for every node never evicts: no limit.)
-  const uint32_t max_active = (resumable && idx->slab_rows < idx->nvec)
-                                  ? (uint32_t)std::max<uint64_t>(1, idx->slab_rows / 256) : (uint32_t)nq;
+  // (a hop parked in the heap-exact kernel may hold a whole adjacency row of any length)
+  const uint64_t hop_rows = 2 * std::max<uint64_t>(128, tl ? 128 : idx->max_degree);
+  const uint32_t max_active = idx->slab_rows < idx->nvec
+                                  ? (uint32_t)std::max<uint64_t>(1, idx->slab_rows / hop_rows) : (uint32_t)nq;
   uint32_t active = (uint32_t)std::min<uint64_t>(nq, max_active);
   uint32_t next_fresh = active;  // queries [next_fresh, nq) have not been started
+  uint32_t nxl = 0;              // queries this round hands straight to the heap-exact kernel
   bool listed = active < nq;
-  if (listed) {
+  if (!resumable) {
+    active = 0;  // an ordinary launch over all queries every round (round fields stay 0)
+    listed = false;
+  } else if (exact_only) {  // no traversal kernel in front: the round's queries are the heap-exact kernel's queue
+    for (uint32_t i = 0; i < active; ++i) ws.h_xlist[i] = i;
+    nxl = active;
+    active = 0;
+    listed = true;
+  } else if (listed) {
     for (uint32_t i = 0; i < active; ++i) ws.h_qlist[i] = i;
     hipLaunchKernelGGL(copy_u32_kernel, dim3(16), dim3(256), 0, st, ws.h_qlist, ws.qlist, (uint64_t)active);
   }
-  struct RoundReset {  // the lane goes back with its round fields cleared whatever happens below
+  struct RoundReset {  // the lane goes back with its round fields cleared whatever happens below,
+    const isl_index* idx;  // and no slot of the heap-exact kernel's pool stays with a query of this call
     isl::SearchWorkspace& w;
-    ~RoundReset() { w.round_active = 0; w.round_listed = false; }
-  } reset{ws};
+    hipStream_t st;
+    ~RoundReset() {
+      w.round_active = 0;
+      w.round_x = 0;
+      w.round_xpark = false;
+      w.round_listed = false;
+      if (idx->pool.slots && idx->pool.locks) {
+        (void)hipMemsetAsync(idx->pool.locks, 0, (size_t)idx->pool.slots * 4, st);
+        (void)hipStreamSynchronize(st);
+      }
+    }
+  } reset{idx, ws, st};
   uint32_t* h_taken = ws.h_head + 15;  // (word 15 of the pinned ticket mirror is otherwise unused)
   // Every query in flight advances by at least one hop per round, and a query makes at most a few
   // times ef hops with new rows: the cap scales with the number of groups the batch is worked
@@ -1008,7 +1070,9 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
   uint32_t stalled = 0;
   std::vector<uint32_t> again;  // two-level search: queries to start over with a larger queue window
   for (;;) {
-    ws.round_active = resumable ? active : 0u;
+    ws.round_active = active;
+    ws.round_x = nxl;
+    ws.round_xpark = x_park;
     ws.round_listed = listed;
     idx->round_no += 1;
     ISL_TRY(search_enqueue(idx, ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, user_stream, mode, tl));
@@ -1018,10 +1082,22 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
     rounds += 1;
     if (resumable) {  // next round: the queries that are waiting for rows, topped up with fresh ones
       uint32_t na = 0;
+      nxl = 0;
+      // queries parked in the heap-exact kernel go straight back to its queue (in front: they hold slots);
+      // the others that wait for rows go through the traversal kernel again -- or, when there is none in
+      // front (ef > 512, long rows), to that queue as well
       for (uint64_t i = 0; i < next_fresh; ++i)
-        if (ws.h_status[i] == QS_BLOCKED) ws.h_qlist[na++] = (uint32_t)i;
-      while (na < max_active && !again.empty()) { ws.h_qlist[na++] = again.back(); again.pop_back(); }
-      while (na < max_active && next_fresh < nq) ws.h_qlist[na++] = next_fresh++;
+        if (ws.h_status[i] == QS_BLOCKED_X) ws.h_xlist[nxl++] = (uint32_t)i;
+      for (uint64_t i = 0; i < next_fresh; ++i)
+        if (ws.h_status[i] == QS_BLOCKED) {
+          if (exact_only) ws.h_xlist[nxl++] = (uint32_t)i;
+          else ws.h_qlist[na++] = (uint32_t)i;
+        }
+      while (na + nxl < max_active && !again.empty()) { ws.h_qlist[na++] = again.back(); again.pop_back(); }
+      while (na + nxl < max_active && next_fresh < nq) {
+        if (exact_only) ws.h_xlist[nxl++] = next_fresh++;
+        else ws.h_qlist[na++] = next_fresh++;
+      }
       if (!na && tl) {
         // every query has run to its end; those whose queue window was too small start over -- alone,
         // nothing is parked now -- with a window four times the size (and a state block to match)
@@ -1039,11 +1115,11 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
       }
       active = na;
       listed = true;
-      if (!active) {  // now the statuses are final
+      if (!active && !nxl) {  // now the statuses are final
         ISL_TRY(search_statuses(ws, nq, nullptr));
         break;
       }
-      hipLaunchKernelGGL(copy_u32_kernel, dim3(16), dim3(256), 0, st, ws.h_qlist, ws.qlist, (uint64_t)na);
+      if (na) hipLaunchKernelGGL(copy_u32_kernel, dim3(16), dim3(256), 0, st, ws.h_qlist, ws.qlist, (uint64_t)na);
     } else if (!misses) {
       break;
     }
@@ -1069,9 +1145,7 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
     // its blocked queries from their start needs their whole traversal resident and never will be.
     if (take == 0 && ++stalled >= (resumable ? 3u : 1u))
       return isl::fail(ISL_ERR_SEARCH, "Search error: the recompute provider's row cache (%llu rows) is too small "
-                       "for this batch (queries answered by the heap-exact or the two-level kernel re-run from "
-                       "their start and need the rows of their whole traversal resident)",
-                       (unsigned long long)idx->slab_rows);
+                       "for this batch (no missing row could be placed)", (unsigned long long)idx->slab_rows);
     if (take) stalled = 0;
     ISL_TRY(isl::encoder_embed_nodes(idx->enc, idx->d_tokens, idx->d_lens, idx->tok_L, ws.uniq, take,
                                      idx->enc_normalize, idx->d_emb, idx->emb_stride, st, ws.uslots));
@@ -1255,7 +1329,7 @@ bool any_lane_busy(const isl_index* idx) {
 }
 
 void free_exact_pool(ExactPool& pl) {
-  void* ptrs[] = {pl.cand_d, pl.cand_id, pl.vis_bits, pl.ulist, pl.locks};
+  void* ptrs[] = {pl.cand_d, pl.cand_id, pl.vis_bits, pl.ulist, pl.locks, pl.xstate};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   pl = ExactPool{};

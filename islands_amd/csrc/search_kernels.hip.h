@@ -25,7 +25,8 @@ enum : uint32_t {
   QS_REDO = 0x100,     // fast kernel gave up -> exact kernel
   QS_SCRATCH = 0x101,  // exact kernel ran out of candidate scratch
   QS_REPLAY = 0x102,   // result-heap order needed: replay kernel re-orders from the push log
-  QS_BLOCKED = 0x103   // recompute provider: a needed row is not materialised yet (ids reported)
+  QS_BLOCKED = 0x103,  // recompute provider: a needed row is not materialised yet (ids reported)
+  QS_BLOCKED_X = 0x104 // ... and the query is parked in the heap-exact kernel (it keeps its pool slot)
 };
 
 struct SearchParams {
@@ -70,6 +71,11 @@ struct SearchParams {
   uint32_t ulist_cap;
   uint32_t* pool_locks;  // [pool_slots] lock word per slot of the shared exact-kernel scratch pool
   uint32_t pool_slots;
+  // recompute provider: queries parked in the heap-exact kernel.  xslot[q] = 1 + the pool slot query q
+  // keeps across rounds (0 = none); xstate = [pool_slots][xstate_words]: 16 scalars, then the result heap
+  uint32_t* xslot;
+  uint32_t* xstate;
+  uint32_t xstate_words;
   // graph under construction (build.hip): row i = adj[i * ell_w .. + ell_deg[i]), `off` unused
   uint32_t ell_w;
   const uint32_t* ell_deg;
@@ -1072,6 +1078,48 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
     uint32_t nredo = *((volatile uint32_t*)&p.ticket[1]);
     if (t >= nredo) break;
     const uint32_t qi = p.redo[t];
+    // Recompute provider (p.xslot): a query that meets an absent row parks here too -- candidate heap,
+    // visited bitmap and hop list stay in its pool slot, which it keeps (lock held) across the rounds;
+    // result heap and scalars go to the slot's state block.  A slot is then claimed per query, and a
+    // query that finds none free gives up for this round (QS_BLOCKED: it starts over later) instead of
+    // spinning -- every slot may be held by a parked query.
+    bool xresumed = false;
+    if (p.xslot) {
+      const uint32_t xs = uni(p.xslot[qi]);
+      uint32_t sl = 0xFFFFFFFFu;
+      if (xs) {
+        sl = xs - 1u;
+        xresumed = true;
+      } else if (slot != 0xFFFFFFFFu) {
+        sl = slot;  // the slot this workgroup still holds from its previous (finished) query
+      } else {
+        if (lane == 0) {
+          for (uint32_t tries = 0; tries < 2u * p.pool_slots && sl == 0xFFFFFFFFu; ++tries) {
+            const uint32_t c = (blockIdx.x + tries) % p.pool_slots;
+            if (atomicCAS(&p.pool_locks[c], 0u, 1u) == 0u) sl = c;
+          }
+        }
+        sl = uni(sl);
+        if (sl == 0xFFFFFFFFu) {
+          if (lane == 0) {
+            p.status[qi] = QS_BLOCKED;
+            p.out_count[qi] = 0;
+            p.ctr[qi * 4 + 0] = 0; p.ctr[qi * 4 + 1] = 0; p.ctr[qi * 4 + 2] = 0; p.ctr[qi * 4 + 3] = 0;
+          }
+          continue;
+        }
+      }
+      if (sl != slot) {
+        // (a parked query's slot while this workgroup holds another: that one goes back first)
+        if (slot != 0xFFFFFFFFu && lane == 0) atomicExch(&p.pool_locks[slot], 0u);
+        slot = sl;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        cand_d = p.cand_d + (size_t)slot * p.cand_cap;
+        cand_i = p.cand_id + (size_t)slot * p.cand_cap;
+        vis = p.vis_bits + (size_t)slot * p.vis_words;
+        ulist = p.ulist + (size_t)slot * p.ulist_cap;
+      }
+    } else
     if (slot == 0xFFFFFFFFu) {
       uint32_t sl = 0;
       if (lane == 0) {
@@ -1092,7 +1140,7 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
       ulist = p.ulist + (size_t)slot * p.ulist_cap;
     }
 
-    for (uint64_t i = lane; i < p.vis_words; i += 64) vis[i] = 0u;
+    if (!xresumed) { for (uint64_t i = lane; i < p.vis_words; i += 64) vis[i] = 0u; }
     const float q_norm = load_query<METRIC>(p.queries + (uint64_t)qi * p.d, p.d, qs);
     __threadfence_block();
 
@@ -1100,7 +1148,27 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
     uint32_t status = QS_OK;
     uint64_t payload = 0;
     uint32_t cH = 0, cE = 0, cV = 0, cP = 0;
+    uint32_t x_nu = 0, x_keep = 0;
+    bool x_have_hop = false, x_parked = false;
+    uint32_t* xst = p.xstate ? p.xstate + (size_t)slot * p.xstate_words : nullptr;
 
+    if (xresumed) {
+      // the parked hop: candidate heap, bitmap and the hop's unvisited ids are where they were left
+      cH = xst[0]; cE = xst[1]; cV = xst[2]; cP = xst[3];
+      x_nu = xst[4]; x_keep = xst[5];
+      const uint32_t rl = xst[6];
+      if (lane == 0) {
+        rlen = rl;
+        clen = (uint64_t)xst[7] | ((uint64_t)xst[8] << 32);
+      }
+      for (uint32_t i = lane; i < rl; i += 64) {
+        res_d[i] = __uint_as_float(xst[16 + i]);
+        res_i[i] = xst[16 + (ef + 1) + i];
+      }
+      x_have_hop = true;
+      __threadfence_block();
+      __syncthreads();
+    } else
     if ((uint64_t)p.entry >= p.nvec) {
       status = QS_NODE_NOT_FOUND;
       payload = p.entry;
@@ -1161,6 +1229,14 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
     }
 
     while (status == QS_OK) {
+      uint32_t nu = 0, keep = 0;
+      if (x_have_hop) {  // a parked hop is evaluated before anything is popped
+        x_have_hop = false;
+        nu = x_nu;
+        keep = x_keep;
+        goto x_hop_ready;
+      }
+      {
       // lane 0: candidates.pop() + termination test, leann.rs:922-928
       if (lane == 0) {
         uint32_t go = 0, cid = 0;
@@ -1185,7 +1261,6 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
       cH += 1;
       cE += deg;
       // unvisited = neighbors.filter(visited.insert), leann.rs:933-937
-      uint32_t nu = 0;
       for (uint32_t base = 0; base < deg; base += 64) {
         bool active = base + lane < deg;
         uint32_t nid = active ? p.adj[o0 + base + lane] : 0u;
@@ -1211,7 +1286,7 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
       if (lane == 0) ctl[2] = (uint32_t)rlen;
       __syncthreads();
       rl_now = ctl[2];
-      uint32_t keep = prune_keep(p.prune_ratio, p.prune_strategy, nu, rl_now, ef);
+      keep = prune_keep(p.prune_ratio, p.prune_strategy, nu, rl_now, ef);
       // compute_embeddings_batch over all kept ids first, leann.rs:947
       uint32_t first_bad = 0xFFFFFFFFu;
       for (uint32_t base = 0; base < keep && first_bad == 0xFFFFFFFFu; base += 64) {
@@ -1224,6 +1299,8 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
         payload = first_bad;
         break;
       }
+      }
+    x_hop_ready:
       if (p.slot_of) {  // recompute provider: every kept row must be materialised
         bool all_here = true;
         for (uint32_t base = 0; base < keep; base += 64) {
@@ -1231,7 +1308,27 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
           const uint32_t uid = (uint32_t)lane < R ? ulist[base + lane] : 0u;
           if (!rows_present(p, uid, R)) all_here = false;
         }
-        if (!all_here) { status = QS_BLOCKED; break; }
+        if (!all_here) {
+          status = QS_BLOCKED;
+          if (p.xslot) {  // park: the slot stays with the query
+            status = QS_BLOCKED_X;
+            if (lane == 0) {
+              ctl[2] = (uint32_t)rlen;
+              xst[0] = cH; xst[1] = cE; xst[2] = cV; xst[3] = cP;
+              xst[4] = nu; xst[5] = keep; xst[6] = (uint32_t)rlen;
+              xst[7] = (uint32_t)clen; xst[8] = (uint32_t)(clen >> 32);
+              p.xslot[qi] = slot + 1u;
+            }
+            __syncthreads();
+            const uint32_t rl = ctl[2];
+            for (uint32_t i = lane; i < rl; i += 64) {
+              xst[16 + i] = __float_as_uint(res_d[i]);
+              xst[16 + (ef + 1) + i] = res_i[i];
+            }
+            x_parked = true;
+          }
+          break;
+        }
       }
       cV += keep;
       for (uint32_t base = 0; base < keep && status == QS_OK; base += 64) {
@@ -1274,7 +1371,8 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
     }
 
     // results.into_iter() (array order) + stable sort by distance, leann.rs:984-986
-    if (lane == 0) {
+    if (lane == 0 && status != QS_OK) ctl[5] = 0;  // (nothing is returned for a failed or parked query)
+    if (lane == 0 && status == QS_OK) {
       for (uint64_t i = 1; i < rlen; ++i) {
         float d = res_d[i];
         uint32_t id = res_i[i];
@@ -1306,8 +1404,10 @@ __global__ __launch_bounds__(64) void leann_search_exact(SearchParams p) {
       p.ctr[qi * 4 + 1] = cE;
       p.ctr[qi * 4 + 2] = cV;
       p.ctr[qi * 4 + 3] = cP;
+      if (p.xslot && !x_parked) p.xslot[qi] = 0u;  // (a resumed query that came to its end gives the slot up below)
     }
     __syncthreads();
+    if (x_parked) slot = 0xFFFFFFFFu;  // the slot belongs to the parked query now, lock held
   }
   if (slot != 0xFFFFFFFFu) {
     __syncthreads();

@@ -300,3 +300,35 @@ def test_recompute_indexes_release_their_device_memory(orc):
     # four prepared lanes hold ~15 MB of parked-query state each here: a leak of that would show as
     # several hundred MB over six indexes
     assert free0 - free1 < 32 << 20, (free0, free1)
+
+
+def test_recompute_heap_exact_kernel_parks_and_resumes(orc):
+    """Queries answered by the heap-exact kernel -- ef beyond 512 (no traversal kernel in front), rows past
+    128 ids, equal embeddings (ties hand a query over) -- over a row cache far smaller than their traversal:
+    round 2 re-ran a blocked query from its start and failed with "row cache too small"; now the query
+    parks in its slot of the scratch pool and resumes in the hop it stopped at.  ids, distance bits and
+    counters equal the in-memory provider's."""
+    from _data import random_csr
+    # min_len = 1: many rows are bare topic prefixes -> equal embeddings -> ties
+    for (seed, min_len, deg, ef, rows) in ((11, 9, 20, 600, 512), (5, 1, 24, 64, 300), (7, 9, 150, 100, 700)):
+        cfg, enc, tok, lens, emb = _recompute_case(orc, n=1600, seed=seed, min_len=min_len)
+        n = emb.shape[0]
+        off, nb = random_csr(n, deg, 3)
+        csr = orc.Csr(off, nb, entry_point=5)
+        g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels, entry_point=5,
+                        num_nodes=n, degree_counts=csr.degree_counts)
+        q = emb[::67] + np.float32(0.02)
+        mem_idx = ia.LeannIndex.from_csr(g, None, dimension=64).upload(0)
+        mem_idx.set_embeddings(emb)
+        want = mem_idx.search_batch(q, 10, ef)
+        ws = mem_idx.last_stats()
+        rec_idx = ia.LeannIndex.from_csr(g, None, dimension=64).upload(0)
+        rec_idx.set_recompute_provider(enc, tok, lens, cache_rows=rows)
+        got = rec_idx.search_batch(q, 10, ef)
+        st = rec_idx.last_stats()
+        assert got[2].tolist() == want[2].tolist() and got[0].tolist() == want[0].tolist(), (seed, ef, rows)
+        assert got[1].view(np.uint32).tolist() == want[1].view(np.uint32).tolist()
+        for f in ("expansions", "edges", "evals", "pushes"):
+            assert st[f] == ws[f], (f, seed, ef, rows)
+        assert ws["exact_path"] > 0 or ef > 512    # the case does go through the heap-exact kernel
+        assert st["encoded_nodes"] >= rows          # the slab turned over
