@@ -309,10 +309,13 @@ def test_recompute_heap_exact_kernel_parks_and_resumes(orc):
     parks in its slot of the scratch pool and resumes in the hop it stopped at.  ids, distance bits and
     counters equal the in-memory provider's."""
     from _data import random_csr
-    # min_len = 1: many rows are bare topic prefixes -> equal embeddings -> ties
-    for (seed, min_len, deg, ef, rows) in ((11, 9, 20, 600, 512), (5, 1, 24, 64, 300), (7, 9, 150, 100, 700)):
-        cfg, enc, tok, lens, emb = _recompute_case(orc, n=1600, seed=seed, min_len=min_len)
+    for (seed, dup, deg, ef, rows) in ((11, False, 20, 600, 512), (5, True, 24, 64, 300), (7, False, 150, 100, 700)):
+        cfg, enc, tok, lens, emb = _recompute_case(orc, n=1600, seed=seed, min_len=9)
         n = emb.shape[0]
+        if dup:  # a quarter of the nodes are copies of others: equal embeddings, equal distances -> ties
+            tok[n // 2: n // 2 + n // 4] = tok[:n // 4]
+            lens[n // 2: n // 2 + n // 4] = lens[:n // 4]
+            emb[n // 2: n // 2 + n // 4] = emb[:n // 4]   # (an embedding does not depend on what it is batched with)
         off, nb = random_csr(n, deg, 3)
         csr = orc.Csr(off, nb, entry_point=5)
         g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels, entry_point=5,
