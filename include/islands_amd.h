@@ -480,7 +480,9 @@ isl_status isl_encoder_embed(isl_encoder* enc, const int64_t* input_ids, const i
  * across all its queries.  keep_rows = 0 forgets every row when a call returns (pure recompute),
  * 1 keeps them as an embedding cache.  The encoder is borrowed and must outlive the index;
  * its hidden size becomes the index dimension; `normalize` as in isl_encoder_embed.
- * Results equal those of the in-memory provider holding the same embeddings. */
+ * Results equal those of the in-memory provider holding the same embeddings.  Every search kernel
+ * parks a query that meets an absent row and resumes it there once the row is encoded, so the row
+ * cache may be far smaller than a traversal (floor: 256 rows). */
 isl_status isl_set_recompute_provider(isl_index* idx, isl_encoder* enc, const uint16_t* tokens,
                                       const uint16_t* lengths, uint64_t n, uint64_t L,
                                       int32_t normalize, int32_t keep_rows, int32_t mem);
