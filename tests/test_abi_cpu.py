@@ -175,3 +175,24 @@ def test_every_compute_family_fails_loudly_without_gpu():
         with pytest.raises(ia.CoreError) as e:
             call()
         assert e.value.kind == "Device", (i, e.value.kind, str(e.value))
+
+
+def test_shard_exchange_entry_points_fail_loudly_without_gpu():
+    """The multi-GPU entry points are host-callable without a card only as far as they need no device:
+    RCCL's unique id is handed out (librccl is loaded on first use), a group or a sharded searcher
+    is not -- Device, never a host-side stand-in for the exchange."""
+    import ctypes as C
+    if ia.device_count() > 0:
+        pytest.skip("a GPU is present")
+    lib = _ffi.lib()
+    uid = (C.c_uint8 * 128)()
+    assert lib.isl_shard_unique_id(uid) == 0 and any(bytes(uid))
+    h = C.c_void_p()
+    cb = _ffi.SHARD_ALLGATHER_FN(lambda u, s, r, n: 0)
+    assert lib.isl_shard_group_create_host(0, 2, 0, cb, None, C.byref(h)) == 100 and not h.value   # ISL_ERR_DEVICE
+    assert lib.isl_shard_group_create(0, 1, 0, uid, C.byref(h)) == 100 and not h.value
+    assert lib.isl_shard_group_create_host(0, 2, 5, cb, None, C.byref(h)) == 101                   # rank out of range
+    idx = ia.LeannIndex.with_defaults()
+    s = C.c_void_p()
+    assert lib.isl_sharded_searcher_new(idx._h, None, 0, None, 2, C.byref(s)) == 100 and not s.value
+    assert lib.isl_shard_record_bytes(1024, 10) == 1024 * 10 * 12 + 1024 * 4
