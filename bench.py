@@ -349,7 +349,10 @@ def main():
         # so ranks that also run the exchange's side stream and RCCL's own keep a margin.
         # (a batch of fewer than 1024 queries fills a fraction of the chip's wave slots: more of them in
         # flight, up to the 32 lanes -- config 2's 256-query batches)
-        auto_depth = (16 if nq >= 1024 else min(32, -(-16 * 1024 // max(nq, 1)))) if world == 1 else 12
+        # Round 4: all 32 lanes on one GPU.  Over a long run 16 and 32 in flight are the same rate;
+        # over the driver's 20 steps all batches are then on the device from the start and the region ends
+        # 0.3-0.8 ms earlier (profiles/r04_single_launch_20480.json: 14.6-14.9 ms against 15.0-15.7).
+        auto_depth = 32 if world == 1 else 12
         depth = max(1, min(args.pipeline if args.pipeline > 0 else auto_depth, 32))
         idx.prepare(nq, ef, k, depth)
         torch.cuda.synchronize()

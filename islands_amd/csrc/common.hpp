@@ -101,6 +101,7 @@ struct SearchWorkspace {
   uint32_t* h_head = nullptr;
   uint64_t h_cap = 0;
   uint64_t* d_prof = nullptr;    // ISL_DEBUG phase timers of the call in flight
+  uint64_t* d_tline = nullptr;   // ISL_TIMELINE: [nq][2] start / end ticks of every query of the call in flight
   uint32_t* q_entry = nullptr;   // HnswGraph: [2][nq] layer-0 entry and descent evaluations per query
   uint64_t q_entry_cap = 0;
   // recompute provider: node ids whose rows a search round found absent, and their unique set

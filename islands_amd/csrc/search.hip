@@ -510,6 +510,15 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
     ISL_HIP(hipMemset(ws.d_prof, 0, nq * 64));
   }
   p.prof = ws.d_prof;
+  // ISL_TIMELINE=<file>: start / end tick of every query of every call, appended at wait time
+  // (measurement aid: where a run's fill and drain go; tools/timeline.py reads the file)
+  static const char* tline_env = getenv("ISL_TIMELINE");
+  if (ws.d_tline) { (void)hipFree(ws.d_tline); ws.d_tline = nullptr; }
+  if (tline_env && !warm) {
+    ISL_HIP(hipMalloc(&ws.d_tline, nq * 16));
+    ISL_HIP(hipMemset(ws.d_tline, 0, nq * 16));
+  }
+  p.tline = ws.d_tline;
   p.replay = ws.replay;
   p.plog = reinterpret_cast<uint2*>(ws.plog);
   p.plog_cap = plog_cap;
@@ -739,6 +748,20 @@ isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws, uint32_
     ss.edges += ctr[i * 4 + 1];
     ss.evals += ctr[i * 4 + 2];
     ss.pushes += ctr[i * 4 + 3];
+  }
+  if (ws.d_tline) {
+    std::vector<uint64_t> tl(nq * 2 + 2);
+    tl[0] = 0x154C494E45ull;  // record header: magic, query count
+    tl[1] = nq;
+    ISL_HIP(hipMemcpy(tl.data() + 2, ws.d_tline, nq * 16, hipMemcpyDeviceToHost));
+    (void)hipFree(ws.d_tline);
+    ws.d_tline = nullptr;
+    static std::mutex tl_mu;
+    std::lock_guard<std::mutex> lock(tl_mu);
+    if (FILE* f = fopen(getenv("ISL_TIMELINE"), "ab")) {
+      fwrite(tl.data(), 8, tl.size(), f);
+      fclose(f);
+    }
   }
   if (d_prof) {
     std::vector<uint64_t> pr(nq * 8);

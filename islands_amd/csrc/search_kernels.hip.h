@@ -56,6 +56,7 @@ struct SearchParams {
   uint32_t* redo;    // [nq] queries for the exact kernel
   uint32_t* replay;  // [nq] queries for the replay kernel
   uint64_t* prof;    // optional [nq][8] phase timers (100 MHz ticks), ISL_DEBUG only
+  uint64_t* tline;   // optional [nq][2]: start tick of every query (100 MHz); its duration | hops << 40; ISL_TIMELINE only
   uint2* plog;       // [nq][plog_cap] (distance bits, id) of every results.push, in order
   uint32_t plog_cap;
   uint32_t hbits;    // LDS visited table: 1 << hbits entries
@@ -1008,6 +1009,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void le
       p.ctr[qi * 4 + 1] = cE;
       p.ctr[qi * 4 + 2] = cV;
       p.ctr[qi * 4 + 3] = cP;
+      if (p.tline) {
+        p.tline[qi * 2] = t_start;
+        p.tline[qi * 2 + 1] = ((__builtin_amdgcn_s_memrealtime() - t_start) & 0xFFFFFFFFFFull) | ((uint64_t)cH << 40);
+      }
       if (p.prof) {
         p.prof[qi * 8 + 0] = tp0; p.prof[qi * 8 + 1] = tp1; p.prof[qi * 8 + 2] = tp2; p.prof[qi * 8 + 3] = tp3;
         p.prof[qi * 8 + 4] = ngroups; p.prof[qi * 8 + 5] = nhops_rows;
