@@ -41,6 +41,13 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+GRAPH_BUILDERS = {
+    "harness": "the harness (tools/synth.py::build_graph: k-means medoid levels flattened into one layer, "
+               "diversified links, parent->child and reverse edges)",
+    "knn": "exact 30-NN lists (the library's brute force) + reverse edges, truncated to 60, entry = medoid",
+    "product": "the library's isl_index_build = the reference's LeannIndex::build rule (leann.rs:560-833), "
+               "4096 nodes per step",
+}
 
 
 def log(msg):
@@ -52,6 +59,41 @@ def algorithmic_bytes(st: dict, d: int, k: int, elem: int = 4) -> float:
     """V*d*s + 4*E + 8*H + 4*d + 12*k per query, summed over a batch."""
     return (st["evals"] * d * elem + 4 * st["edges"] + 8 * st["expansions"] +
             st["queries"] * (4 * d + 12 * k))
+
+
+def host_cpu_info() -> dict:
+    """What the CPU baseline ran on: `nproc` (logical CPUs this process may run on), the model name
+    lscpu prints, the physical cores among them (distinct (package, core) pairs of /proc/cpuinfo), and
+    the cgroup CPU quota when there is one (a box may hand a process fewer CPU-seconds per second than
+    it has cores)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    model, cores, cur = "", set(), {}
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh.read().split("\n") + [""]:
+                if ":" in line:
+                    k_, v_ = (t.strip() for t in line.split(":", 1))
+                    cur[k_] = v_
+                elif cur:
+                    if not model:
+                        model = cur.get("model name", "")
+                    if int(cur.get("processor", -1)) in allowed:
+                        cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                    cur = {}
+    except OSError:
+        pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q_, p_ = fh.read().split()[:2]
+            quota = None if q_ == "max" else round(int(q_) / int(p_), 2)
+    except (OSError, ValueError):
+        pass
+    return {"nproc": len(allowed), "logical_cpus_of_the_box": os.cpu_count(), "model": model,
+            "physical_cores_available": len(cores) or len(allowed), "cgroup_cpu_quota": quota}
 
 
 def cpu_baseline(x, offsets, neighbours, entry, qsets, k, ef, leg_s=10.0):
@@ -73,12 +115,8 @@ def cpu_baseline(x, offsets, neighbours, entry, qsets, k, ef, leg_s=10.0):
     log(f"cpu_baseline: host copy of the index took {time.time() - t0:.1f}s")
     for i in range(4):  # page the index in
         orc.leann_search(csr, xv, q[i], k, ef, copy_per_node=True)
-    ncores = os.cpu_count() or 1
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
-    threads = max(1, min(ncores, 64))
+    host = host_cpu_info()
+    threads = max(1, host["physical_cores_available"])  # all physical cores
 
     def leg(nthreads, seconds):
         done = [0] * nthreads
@@ -109,6 +147,8 @@ def cpu_baseline(x, offsets, neighbours, entry, qsets, k, ef, leg_s=10.0):
     return {
         "value": round(nm / dtm, 2), "unit": "queries/s", "cores": threads, "kind": "port",
         "value_1thread": round(n1 / dt1, 2),
+        "threads_used": threads, "nproc": host["nproc"], "cpu_model": host["model"],
+        "host": host,
         "sample": f"{nm} queries in {dtm:.1f} s on {threads} threads (thread t takes every {threads}th query of "
                   f"the run's {len(qsets)} batches; ctypes releases the GIL), {n1} queries in {dt1:.1f} s on 1 "
                   "thread; copy-per-node provider as in leann.rs:145-154; same graph, ef and k",
@@ -134,7 +174,7 @@ def measure_traffic(args):
              "--warmup", "1", "--pipeline", "1", "--nodes", str(args.nodes), "--dim", str(args.dim), "--nq",
              str(args.nq), "--k", str(args.k), "--ef", str(args.ef), "--per-cluster", str(args.per_cluster),
              "--row-dtype", args.row_dtype, "--dataset", args.dataset, "--distinct-batches",
-             str(args.distinct_batches), "--no-cpu-baseline", "--no-host-path", "--no-traffic"]
+             str(args.distinct_batches), "--graph", args.graph, "--no-cpu-baseline", "--no-host-path", "--no-traffic"]
     cmd = [rp, "--pmc", "FETCH_SIZE", "--kernel-include-regex", "leann_search_fast", "-d", out, "-o", "p",
            "--output-format", "csv", "--"] + child
     env = dict(os.environ, TMPDIR="/tmp")
@@ -235,6 +275,15 @@ def main():
                     help="G: the headline clustered mixture; U: i.i.d. uniform [-1,1) rows as in "
                          "benches/hnsw_benchmarks.rs:9-14 (SURVEY 8d asks for both; no cluster structure, "
                          "so recall at ef=128 is whatever the data allows)")
+    ap.add_argument("--graph", choices=["harness", "knn", "product"], default="harness",
+                    help="who builds the graph the search walks.  harness (headline): tools/synth.py::build_graph "
+                         "(k-means medoid levels flattened into one layer, diversified links); knn: every node's 30 "
+                         "exact nearest neighbours by the library's own brute force + reverse edges, truncated to 60 "
+                         "-- no hierarchy, no diversification; product: the library's isl_index_build, i.e. the "
+                         "reference's LeannIndex::build rule (leann.rs:560-833), batch mode")
+    ap.add_argument("--ef-sweep", default="256,512",
+                    help="when recall@10 at --ef misses 0.95: the larger ef values tried (one after the other, "
+                         "until one reaches it); empty = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer pipelined measurement")
     ap.add_argument("--no-traffic", action="store_true",
@@ -329,14 +378,33 @@ def main():
         torch.cuda.synchronize()
         log(f"rows [{lo},{hi}) generated in {time.time() - t0:.1f}s")
         t0 = time.time()
-        offsets, neighbours, entry = synth.build_graph(x, m0=60)
+        cfg = ia.LeannConfig.paper_default()
+        idx = None
+        if args.graph == "knn":
+            offsets, neighbours, entry = synth.build_knn_graph(x, k=30, m0=60, progress=log)
+        elif args.graph == "product":
+            # LeannIndex::build on the device (build.hip), 4096 nodes per step; its CsrGraph comes back through
+            # to_bytes (bincode layout, api_index.hip): 75-byte config, then node_offsets and neighbors
+            idx = ia.LeannIndex.build(x.cpu().numpy(), cfg, batch=4096, device=local_rank)
+            raw = np.frombuffer(idx.to_bytes(), dtype=np.uint8)
+            n_off = int(raw[75:83].view(np.uint64)[0])
+            off_h = raw[83:83 + 8 * n_off].view(np.uint64)
+            n_nb = int(raw[83 + 8 * n_off:91 + 8 * n_off].view(np.uint64)[0])
+            nb_h = raw[91 + 8 * n_off:91 + 8 * n_off + 8 * n_nb].view(np.uint64)
+            offsets = torch.from_numpy(off_h.astype(np.int64)).to(dev)
+            neighbours = torch.from_numpy(nb_h.astype(np.int32)).to(dev)
+            entry = idx.entry_point()
+            del raw
+        else:
+            offsets, neighbours, entry = synth.build_graph(x, m0=60)
         torch.cuda.synchronize()
         gst = synth.graph_stats(offsets)
-        log(f"graph built in {time.time() - t0:.1f}s: {gst}")
+        log(f"graph ({args.graph}) built in {time.time() - t0:.1f}s: {gst}")
+        graph_build_s = time.time() - t0
         t0 = time.time()
-        cfg = ia.LeannConfig.paper_default()
-        idx = ia.LeannIndex.from_device_csr(offsets.data_ptr(), neighbours.data_ptr(), n_local, entry,
-                                            d, cfg, device=local_rank)
+        if idx is None:
+            idx = ia.LeannIndex.from_device_csr(offsets.data_ptr(), neighbours.data_ptr(), n_local, entry,
+                                                d, cfg, device=local_rank)
         if x16 is not None:
             idx.set_embeddings_bf16(None, device_ptr=x16.data_ptr(), n=n_local, d=d)
         else:
@@ -459,14 +527,33 @@ def main():
         # its clocks (measured: 6 % on the 20-step run).
         gc.collect()
         gc.disable()
-        run(0, args.warmup, False)
-        barrier()
-        trace = [] if os.environ.get("ISL_BENCH_TRACE") else None  # completion times of the timed steps -> stderr
-        t0 = time.perf_counter()
-        agg, recalls = run(args.warmup, args.steps, True)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        gc.enable()
+        # A rank whose warm-up or timed steps fail must not leave the others inside a collective: the
+        # library's exchange is entered by a failing rank too (poisoned record) and its waits are bounded
+        # (shard.hip), so every rank gets here; what happened is then agreed on with one all-reduce of a
+        # per-rank ok flag instead of assumed.
+        failure = None
+        agg, recalls, elapsed = None, [], float("inf")
+        try:
+            run(0, args.warmup, False)
+            barrier()
+            trace = [] if os.environ.get("ISL_BENCH_TRACE") else None  # completion times of the timed steps -> stderr
+            t0 = time.perf_counter()
+            agg, recalls = run(args.warmup, args.steps, True)
+            barrier()
+            elapsed = time.perf_counter() - t0
+        except Exception as e:  # noqa: BLE001
+            failure = e
+        finally:
+            gc.enable()
+        ranks_ok = 1 if failure is None else 0
+        if world > 1:
+            okt = torch.tensor([ranks_ok], device=dev if backend == "nccl" else "cpu", dtype=torch.int64)
+            dist.all_reduce(okt)
+            ranks_ok = int(okt.item())
+        if failure is not None:
+            raise failure
+        if ranks_ok != world:
+            raise RuntimeError(f"only {ranks_ok} of {world} ranks came through the timed region")
         if trace:
             log("step completions (ms after the start of the timed region; kernel ms of the step): " +
                 " ".join(f"{b}:{(t - t0) * 1e3:.2f}/{km:.2f}" for b, t, km in trace) + f"  end {elapsed * 1e3:.2f}")
@@ -477,10 +564,8 @@ def main():
             tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-            # ranks that came through every exchange of the timed region
-            one = torch.ones(1, device=dev if backend == "nccl" else "cpu", dtype=torch.int64)
-            dist.all_reduce(one)
-            ranks_done = int(one.item())
+            # ranks that came through every exchange of the timed region (the ok flags summed above)
+            ranks_done = ranks_ok
             if shard_mode and comm_info.get("comm_ranks") not in (None, ranks_done):
                 raise RuntimeError(f"communicator has {comm_info.get('comm_ranks')} ranks, {ranks_done} completed")
 
@@ -523,9 +608,10 @@ def main():
                 "workload": f"{n_local if args.rehearse_shard else N} x {d} {args.row_dtype} rows resident in HBM (in-memory provider), "
                             + ("hierarchical Gaussian mixture" if args.dataset == "G" else
                                "dataset U: i.i.d. uniform [-1,1) rows (benches/hnsw_benchmarks.rs:9-14)") +
-                            f", graph deg<= 60 (mean {gst['deg_mean']:.1f}), "
+                            f", graph by {GRAPH_BUILDERS[args.graph]}, deg<= 60 (mean {gst['deg_mean']:.1f}), "
                             f"query batch {nq}, k={k}, ef={ef}, cosine",
                 "nodes": N, "dim": d, "query_batch": nq, "k": k, "ef": ef,
+                "graph": args.graph, "graph_build_s": round(graph_build_s, 1),
                 "rehearsed_shard": ({"shard": args.rehearse_shard, "rows": [lo, hi]} if args.rehearse_shard else None),
                 "parallelism": ("single" if world == 1 else
                                 (f"shard{world}: node-id ranges, RCCL all-gather + top-k merge"
@@ -555,6 +641,29 @@ def main():
                 "algorithmic_bytes_per_launch": round(bytes_per_launch, 0),
             },
         }
+        if world == 1 and recall < 0.95 and not args.traffic_child and args.ef_sweep:
+            # "if < 0.95 at ef=128 report the ef that reaches 0.95 and the QPS there" -- one batch
+            # per ef, synchronous, up to the traversal kernel's limit (ef <= 512)
+            sweep = []
+            for ef2 in [int(v) for v in args.ef_sweep.split(",") if int(v) > ef]:
+                o = outs[0]
+                idx.search_batch_device(qsets[0].data_ptr(), nq, d, k, ef2, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+                st2 = idx.last_stats()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                toks = [idx.search_batch_device_async(qsets[b % nb_batches].data_ptr(), nq, d, k, ef2, outs[b][0].data_ptr(),
+                                                      outs[b][1].data_ptr(), outs[b][2].data_ptr())
+                        for b in range(min(depth, 8))]
+                for t_ in toks:
+                    idx.wait_stats(t_)
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t1
+                r2 = synth.recall_at_k(outs[0][0], outs[0][2], truths[0][0])
+                sweep.append({"ef": ef2, "recall_at_10": round(r2, 4), "queries_per_s": round(len(toks) * nq / dt2, 1),
+                              "evals_per_query": round(st2["evals"] / nq, 1)})
+                if r2 >= 0.95:
+                    break
+            result["ef_sweep"] = sweep
         if world == 1 and not args.no_host_path and not args.traffic_child:
             # QPS by SURVEY 8(d): host buffers in, host buffers out (the caller contract of
             # search.rs:150-181 / indexer/service.rs:781-785), `depth` calls in flight through
@@ -587,6 +696,10 @@ def main():
             ref = ref_ids.get((args.steps - 1) % nb_batches)
             same = (bool((torch.from_numpy(houts[(args.steps - 1) % depth][0].astype(np.int64)).to(dev) == ref)
                          .all().item()) if ref is not None else None)
+            # the QPS SURVEY 8(d) defines (H2D of the queries and D2H of the answers inside the timed region),
+            # as a first-class field next to `value` (which this round's bench contract defines on
+            # HBM-resident inputs)
+            result["value_survey_8d"] = round(args.steps * nq / dt, 2)
             result["host_buffer_path"] = {
                 "value": round(args.steps * nq / dt, 2), "unit": "queries/s",
                 "ms_per_step": round(dt / args.steps * 1e3, 3),

@@ -323,7 +323,9 @@ isl_status isl_merge_topk(uint64_t nlists, uint64_t nq, uint64_t k, const uint64
  * all-gather delivers in rank order.  Everything lives on the device (d_id_base: u64[nlists]);
  * the kernel is enqueued on `stream` and nothing is waited for.  *d_flags (u32, zeroed by the
  * caller once) collects bit 0 = a NaN score met (the reference panics, search.rs:231), bit 1 =
- * a list was not ascending; read it when the results are consumed. */
+ * a list was not ascending, bit 2 = a list carried ISL_SHARD_POISON_COUNT as a query's count (its
+ * producer failed that query: the list counts as empty); read it when the results are consumed. */
+#define ISL_SHARD_POISON_COUNT 0xFFFFFFFFu
 uint64_t isl_shard_record_bytes(uint64_t nq, uint64_t k);
 isl_status isl_merge_topk_packed_async(uint64_t nlists, uint64_t nq, uint64_t k, const void* d_records,
                                        uint64_t list_stride, const uint64_t* d_id_base, uint64_t top_k,
@@ -348,7 +350,17 @@ isl_status isl_merge_topk_packed_async(uint64_t nlists, uint64_t nq, uint64_t k,
  *     into recv (rank-major) over host memory, supplied by the caller (MPI, gloo, a socket ...): for
  *     boxes without xGMI between the ranks' cards and for tests where ranks share one card.  The
  *     exchange is then synchronous inside isl_sharded_submit.
- * world == 1 needs no group (pass NULL to isl_sharded_searcher_new). */
+ * world == 1 needs no group (pass NULL to isl_sharded_searcher_new).
+ *
+ * Failure across ranks: MultiIndexSearcher::search propagates the first index's error (`?`,
+ * search.rs:215), so one failing shard fails the whole search -- on EVERY rank, and without leaving
+ * the others inside the collective.  A rank whose shard search cannot be enqueued or fails (wrong
+ * dimension, no lane, a device error, a query that ends in NodeNotFound ...) still takes part in the
+ * batch's all-gather with a record whose counts are ISL_SHARD_POISON_COUNT (the whole batch, or the
+ * failed queries); the merge raises flag bit 2 on every rank and isl_sharded_result returns
+ * ISL_ERR_SEARCH for that batch everywhere (the failing rank reports its own error).  Waits on an
+ * exchange are bounded (ISL_SHARD_TIMEOUT_MS, default 60000): a peer that never arrives is
+ * ISL_ERR_DEVICE naming the batch, not a hang. */
 #define ISL_SHARD_UNIQUE_ID_BYTES 128
 typedef struct isl_shard_group isl_shard_group;
 typedef int32_t (*isl_shard_allgather_fn)(void* user, const void* send, void* recv, uint64_t bytes);
@@ -373,18 +385,27 @@ isl_status isl_sharded_searcher_new(const isl_index* shard, isl_shard_group* grp
                                     const uint64_t* id_base, int32_t depth, isl_sharded_searcher** out);
 void isl_sharded_searcher_free(isl_sharded_searcher* s);
 /* Buffers for `depth` batches of up to max_nq queries / max_k results, and isl_index_prepare on the
- * shard: nothing allocates on the submit path afterwards.  Collective over the ranks with the RCCL
- * transport (the communicator's first all-gather, which sets up its channels, is made here). */
+ * shard: nothing allocates on the submit path afterwards.  Collective over the ranks whenever the
+ * searcher has a group (the RCCL communicator's first all-gather, which sets up its channels, is made
+ * here): the 16 bytes exchanged carry every rank's local outcome, so a rank whose set-up failed still
+ * enters the collective and ALL ranks return an error (the failing one its own, the others
+ * ISL_ERR_SEARCH). */
 isl_status isl_sharded_prepare(isl_sharded_searcher* s, uint64_t max_nq, uint64_t max_k, uint64_t max_ef);
 /* Enqueues one batch (queries on the device, ordered after the work already on `stream`): shard
- * search -> all-gather of the records -> merge.  Every rank must submit the same batches in the
- * same order.  Returns a handle; nothing is waited for (RCCL transport). */
+ * search -> all-gather of the records -> merge.  Every rank must submit the same batches (nq, k) in
+ * the same order.  Returns a handle; nothing is waited for (RCCL transport).  Any free slot is taken
+ * (the one released longest ago).  When this rank's search cannot be enqueued the exchange is made
+ * all the same, with a poisoned record, the call returns the search's error and *handle stays 0 (the
+ * slot is reclaimed behind the exchange); the other ranks learn of it from isl_sharded_result. */
 isl_status isl_sharded_submit(isl_sharded_searcher* s, const float* d_queries, uint64_t nq, uint64_t d,
                               uint64_t k, uint64_t ef, void* stream, uint64_t* handle);
 /* Completes a submitted batch: per-query failures of this rank's shard surface here (the first
- * failing query's CoreError); the merged answers are on the device -- global ids u64[nq][k],
- * distances f32[nq][k], source rank u32[nq][k], counts u32[nq] -- and stay valid until `depth`
- * further batches have been submitted.  `stats` (may be NULL) = this rank's search counters. */
+ * failing query's CoreError), a failure of any other rank's shard as ISL_ERR_SEARCH, a NaN score in
+ * this batch's merge as ISL_ERR_SEARCH (the reference panics, search.rs:231; flags are per batch);
+ * the merged answers are on the device -- global ids u64[nq][k], distances f32[nq][k], source rank
+ * u32[nq][k], counts u32[nq] -- and stay valid until `depth` further batches have been submitted
+ * (slots are reused least-recently-released first).  `stats` (may be NULL) = this rank's search
+ * counters.  The wait for the exchange is bounded (ISL_SHARD_TIMEOUT_MS -> ISL_ERR_DEVICE). */
 isl_status isl_sharded_result(isl_sharded_searcher* s, uint64_t handle, const uint64_t** d_ids,
                               const float** d_dist, const uint32_t** d_src, const uint32_t** d_count,
                               isl_search_stats* stats);
@@ -394,8 +415,8 @@ isl_status isl_sharded_result(isl_sharded_searcher* s, uint64_t handle, const ui
 isl_status isl_sharded_search_batch(isl_sharded_searcher* s, const float* queries, uint64_t nq, uint64_t d,
                                     uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dist,
                                     uint32_t* out_src, uint32_t* out_count);
-/* Merge flags accumulated so far (bit 0: NaN score met, bit 1: a list was not ascending); synchronises
- * the exchange stream. */
+/* Merge flags of all completed batches so far, OR-ed (bit 0: NaN score met, bit 1: a list was not
+ * ascending, bit 2: a rank failed a batch); synchronises the exchange stream. */
 isl_status isl_sharded_flags(isl_sharded_searcher* s, uint32_t* flags);
 
 /* Product-level merge, src/indexer/service.rs:775-801 (IndexerService::search_with_embeddings):
@@ -537,6 +558,12 @@ isl_status isl_hnsw_last_stats(const isl_hnsw* h, isl_search_stats* out);
 isl_status isl_distance_matrix_bf16(int32_t metric, const uint16_t* queries, uint64_t nq, const uint16_t* rows,
                                     uint64_t n, uint64_t d, float* out, int32_t mem, int32_t device,
                                     void* stream);
+/* isl_bruteforce_topk over bf16 rows and queries: blocks of isl_distance_matrix_bf16 + the same running
+ * top-k (ties towards the smaller id), exact under the bf16 GEMM's distances.  Ground truth and exact
+ * kNN lists at sizes where the float32 GEMM would take tens of minutes (10M x 10M x 768). */
+isl_status isl_bruteforce_topk_bf16(int32_t metric, const uint16_t* queries, uint64_t nq, const uint16_t* rows,
+                                    uint64_t n, uint64_t d, uint64_t k, uint64_t* out_ids, float* out_dist,
+                                    uint32_t* out_count, int32_t mem, int32_t device, void* stream);
 
 /* ---- EXTENSION: two-level search with a PQ filter ----
  * "Algorithm 2: Two-Level Search with Hybrid Distance", docs/leann-specification.md:223-275; the

@@ -372,8 +372,8 @@ class ShardedSearcher {
     std::vector<uint64_t> ids(nq * k);
     std::vector<float> dist(nq * k);
     std::vector<uint32_t> src(nq * k), cnt(nq);
-    check(isl_sharded_search_batch(h_, queries.data(), nq, queries.size() / nq, k, ef, ids.data(), dist.data(), src.data(),
-                                   cnt.data()));
+    check(isl_sharded_search_batch(h_, queries.data(), nq, nq ? queries.size() / nq : 0, k, ef, ids.data(), dist.data(),
+                                   src.data(), cnt.data()));
     std::vector<std::vector<ShardedResult>> out(nq);
     for (uint64_t q = 0; q < nq; q++)
       for (uint32_t j = 0; j < cnt[q]; j++) out[q].push_back({ids[q * k + j], dist[q * k + j], src[q * k + j]});

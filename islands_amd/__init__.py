@@ -136,6 +136,19 @@ def bruteforce_topk(metric: DistanceMetric, queries, rows, k: int, device: int =
     return ids[:, :k], dd[:, :k], cnt
 
 
+def bruteforce_topk_bf16(metric: DistanceMetric, queries_bits, rows_bits, k: int, device: int = 0):
+    """bruteforce_topk over bf16 bit patterns (u16): exact under distance_matrix_bf16's distances."""
+    q = np.ascontiguousarray(queries_bits, dtype=np.uint16)
+    r = np.ascontiguousarray(rows_bits, dtype=np.uint16)
+    nq = q.shape[0]
+    ids = np.zeros((nq, max(k, 1)), dtype=np.uint64)
+    dd = np.zeros((nq, max(k, 1)), dtype=np.float32)
+    cnt = np.zeros(nq, dtype=np.uint32)
+    _check(_ffi.lib().isl_bruteforce_topk_bf16(int(metric), _ptr(q), nq, _ptr(r), r.shape[0], q.shape[1], k,
+                                               _ptr(ids), _ptr(dd), _ptr(cnt), MEM_HOST, device, None))
+    return ids[:, :k], dd[:, :k], cnt
+
+
 def normalize_rows(rows, device: int = 0) -> np.ndarray:
     """normalize_vector (distance.rs:125-132) applied to every row; returns a copy."""
     r = _f32(rows).copy()

@@ -255,6 +255,8 @@ namespace isl {
 isl_status search_device_sync(const isl_index* idx, const float* d_queries, uint64_t nq, uint64_t d,
                               uint64_t k, uint64_t ef, uint64_t* d_ids, float* d_dist,
                               uint32_t* d_count, hipStream_t stream);
+// shard.hip: marks the queries of call `token` that failed with ISL_SHARD_POISON_COUNT in d_counts [nq]
+isl_status poison_failed_queries(const isl_index* idx, uint64_t token, uint32_t* d_counts, uint64_t nq, hipStream_t stream);
 isl_status materialise_host_csr(const isl_index* idx);
 // build_distance_tables (pq.rs:307-338) for nq device-resident queries into d_tables [nq][m][K]
 isl_status pq_launch_tables(const isl_pq* pq, const float* d_queries, uint64_t nq, float* d_tables,

@@ -71,7 +71,23 @@ __global__ __launch_bounds__(256) void sumsq_rows_bf16_kernel(const uint16_t* __
 }
 
 // Keeps the k smallest (distance, id) of every query across column chunks: one wave per query,
-// the running list sorted ascending in LDS, ties resolved towards the smaller id.
+// the running list sorted ascending in LDS, ties resolved towards the smaller id.  The scan takes
+// 16 bytes per lane and step (the next step's load is issued before the current one is examined);
+// only values that beat the k-th best so far reach the serial insertion, k ln(n / k) of them over a
+// whole scan of n columns.
+__device__ __forceinline__ void topk_insert(float* bd, uint64_t* bi, uint32_t& cnt, uint32_t k, float nv, uint64_t ni) {
+  if (cnt == k && !(nv < bd[k - 1] || (nv == bd[k - 1] && ni < bi[k - 1]))) return;  // no longer among the k best
+  uint32_t pos = cnt < k ? cnt : k - 1;
+  while (pos > 0 && (nv < bd[pos - 1] || (nv == bd[pos - 1] && ni < bi[pos - 1]))) {
+    bd[pos] = bd[pos - 1];
+    bi[pos] = bi[pos - 1];
+    --pos;
+  }
+  bd[pos] = nv;
+  bi[pos] = ni;
+  if (cnt < k) ++cnt;
+}
+
 __global__ __launch_bounds__(64) void topk_chunk_kernel(const float* __restrict__ dist, uint64_t ld,
                                                         uint32_t cols, uint64_t col0, uint32_t k,
                                                         float* __restrict__ best_d, uint64_t* __restrict__ best_i,
@@ -84,31 +100,41 @@ __global__ __launch_bounds__(64) void topk_chunk_kernel(const float* __restrict_
   for (uint32_t i = lane; i < cnt; i += 64) { bd[i] = best_d[(uint64_t)q * k + i]; bi[i] = best_i[(uint64_t)q * k + i]; }
   __syncthreads();
   const float* row = dist + (uint64_t)q * ld;
-  for (uint32_t c0 = 0; c0 < cols; c0 += 64) {
-    const uint32_t c = c0 + lane;
-    const float v = c < cols ? row[c] : 0.0f;
-    const float kth = cnt == k ? bd[k - 1] : 0.0f;
-    const bool cand = c < cols && (cnt < k || v < kth || (v == kth && col0 + c < bi[k - 1]));
-    uint64_t m = __ballot(cand);
+  const bool vec = (ld & 3u) == 0 && ((uintptr_t)dist & 15u) == 0;
+  const float kInf = __builtin_inff();
+  auto load4 = [&](uint32_t c) -> float4 {  // columns c .. c + 3 of the row, +inf past the end
+    if (vec && c + 4 <= cols) return *reinterpret_cast<const float4*>(row + c);
+    float4 v;
+    v.x = c < cols ? row[c] : kInf;
+    v.y = c + 1 < cols ? row[c + 1] : kInf;
+    v.z = c + 2 < cols ? row[c + 2] : kInf;
+    v.w = c + 3 < cols ? row[c + 3] : kInf;
+    return v;
+  };
+  float4 nxt = load4(lane * 4);
+  for (uint32_t c0 = 0; c0 < cols; c0 += 256) {
+    const uint32_t c = c0 + lane * 4;
+    const float4 v4 = nxt;
+    if (c0 + 256 < cols) nxt = load4(c + 256);
+    const float vs[4] = {v4.x, v4.y, v4.z, v4.w};
+    const bool full = cnt == k;
+    const float kth = full ? bd[k - 1] : 0.0f;
+    const uint64_t kid = full ? bi[k - 1] : 0ull;
+    uint32_t cm = 0;  // which of this lane's four columns may enter the list
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool in = c + j < cols;
+      if (in && (!full || vs[j] < kth || (vs[j] == kth && col0 + c + j < kid))) cm |= 1u << j;
+    }
+    uint64_t m = __ballot(cm != 0);
     while (m) {
       const int l = __ffsll((long long)m) - 1;
       m &= m - 1;
-      const float nv = __shfl(v, l);
-      const uint64_t ni = col0 + c0 + (uint32_t)l;
-      if (lane == 0) {
-        if (cnt == k && !(nv < bd[k - 1] || (nv == bd[k - 1] && ni < bi[k - 1]))) {
-          // no longer among the k best
-        } else {
-          uint32_t pos = cnt < k ? cnt : k - 1;
-          while (pos > 0 && (nv < bd[pos - 1] || (nv == bd[pos - 1] && ni < bi[pos - 1]))) {
-            bd[pos] = bd[pos - 1];
-            bi[pos] = bi[pos - 1];
-            --pos;
-          }
-          bd[pos] = nv;
-          bi[pos] = ni;
-          if (cnt < k) ++cnt;
-        }
+      const uint32_t lm = (uint32_t)__shfl((int)cm, l);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float nv = __shfl(vs[j], l);
+        if (lane == 0 && ((lm >> j) & 1u)) topk_insert(bd, bi, cnt, k, nv, col0 + c0 + (uint32_t)l * 4 + j);
       }
       cnt = (uint32_t)__shfl((int)cnt, 0);
       __syncthreads();
@@ -283,6 +309,74 @@ isl_status isl_bruteforce_topk(int32_t metric, const float* queries, uint64_t nq
       const uint64_t cols = std::min(chunk, n - c0);
       ISL_TRY(launch_distance_gemm(metric, dq, dr + c0 * ldr, qn, rn + c0, blk, nq, cols, ldq, st));
       hipLaunchKernelGGL(topk_chunk_kernel, dim3((uint32_t)nq), dim3(64), lds, st, blk, cols, (uint32_t)cols, c0,
+                         (uint32_t)k, bd, bi, bn);
+    }
+    ISL_HIP(hipGetLastError());
+  }
+  hipMemcpyKind kind = mem == ISL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (k) {
+    ISL_HIP(hipMemcpyAsync(out_ids, bi, nq * k * 8, kind, st));
+    ISL_HIP(hipMemcpyAsync(out_dist, bd, nq * k * 4, kind, st));
+  }
+  ISL_HIP(hipMemcpyAsync(out_count, bn, nq * 4, kind, st));
+  ISL_HIP(hipStreamSynchronize(st));
+  return ISL_OK;
+}
+
+// The same over bf16 rows and queries: distance blocks from the bf16 matrix cores
+// (isl_distance_matrix_bf16's kernel), exact top-k under THOSE distances.  What makes an exact kNN
+// graph or a ground truth over 10M rows a matter of minutes (1.5e17 flops at d = 768).
+isl_status isl_bruteforce_topk_bf16(int32_t metric, const uint16_t* queries, uint64_t nq, const uint16_t* rows,
+                                    uint64_t n, uint64_t d, uint64_t k, uint64_t* out_ids, float* out_dist,
+                                    uint32_t* out_count, int32_t mem, int32_t device, void* stream) {
+  if (nq == 0) return ISL_OK;
+  if (!queries || !out_count || (k && (!out_ids || !out_dist)) || (!rows && n))
+    return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
+  if (k > 1024) return isl::fail(ISL_ERR_UNSUPPORTED, "k <= 1024");
+  if (nq > 0xFFFFFFFFull) return isl::fail(ISL_ERR_UNSUPPORTED, "too many queries");
+  if (d == 0 && n) return isl::fail(ISL_ERR_EMPTY_COLLECTION, "Empty vector collection");
+  if (d % 64) return isl::fail(ISL_ERR_UNSUPPORTED, "bf16 distance matrix: the dimension must be a multiple of 64");
+  ISL_TRY(isl::use_device(device));
+  hipStream_t st = (hipStream_t)stream;
+  Staged s;
+  const uint64_t kk = k ? k : 1;
+  float* bd = (float*)s.alloc(nq * kk * 4);
+  uint64_t* bi = (uint64_t*)s.alloc(nq * kk * 8);
+  uint32_t* bn = (uint32_t*)s.alloc(nq * 4);
+  if (!bd || !bi || !bn) return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed");
+  ISL_HIP(hipMemsetAsync(bn, 0, nq * 4, st));
+  if (n && k) {
+    const uint16_t *dq = queries, *dr = rows;
+    if (mem == ISL_MEM_HOST) {
+      uint16_t* a = (uint16_t*)s.alloc(nq * d * 2);
+      uint16_t* b = (uint16_t*)s.alloc(n * d * 2);
+      if (!a || !b) return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed");
+      ISL_HIP(hipMemcpyAsync(a, queries, nq * d * 2, hipMemcpyHostToDevice, st));
+      ISL_HIP(hipMemcpyAsync(b, rows, n * d * 2, hipMemcpyHostToDevice, st));
+      dq = a;
+      dr = b;
+    }
+    if (((uintptr_t)dq & 15) || ((uintptr_t)dr & 15))
+      return isl::fail(ISL_ERR_INVALID_ARGUMENT, "bf16 matrices must be 16-byte aligned");
+    // column chunks sized so that the distance block stays near 1 GiB (a multiple of 256 columns: the
+    // GEMM's tile, and the top-k scan's 16-byte loads stay aligned in every row)
+    const uint64_t chunk = std::max<uint64_t>(4096, std::min<uint64_t>((n + 255) / 256 * 256,
+                                                                      ((1ull << 28) / std::max<uint64_t>(nq, 1)) / 256 * 256));
+    float* qn = (float*)s.alloc(nq * 4);
+    float* rn = (float*)s.alloc(n * 4);
+    float* blk = (float*)s.alloc(nq * chunk * 4);
+    if (!qn || !rn || !blk) return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed");
+    if (metric != ISL_METRIC_DOT) {
+      hipLaunchKernelGGL(sumsq_rows_bf16_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, dq, nq, (uint32_t)d, qn);
+      for (uint64_t r0 = 0; r0 < n; r0 += 0x7FFFFFFCull)  // grid.x limit (four rows per workgroup)
+        hipLaunchKernelGGL(sumsq_rows_bf16_kernel, dim3((uint32_t)((std::min<uint64_t>(n - r0, 0x7FFFFFFCull) + 3) / 4)),
+                           dim3(256), 0, st, dr + r0 * d, std::min<uint64_t>(n - r0, 0x7FFFFFFCull), (uint32_t)d, rn + r0);
+    }
+    const size_t lds = ((kk * 4 + 7) & ~7ull) + kk * 8;
+    for (uint64_t c0 = 0; c0 < n; c0 += chunk) {
+      const uint64_t cols = std::min(chunk, n - c0);
+      ISL_TRY(launch_distance_gemm_bf16(metric, dq, dr + c0 * d, qn, rn + c0, blk, nq, cols, d, chunk, st));
+      hipLaunchKernelGGL(topk_chunk_kernel, dim3((uint32_t)nq), dim3(64), lds, st, blk, chunk, (uint32_t)cols, c0,
                          (uint32_t)k, bd, bi, bn);
     }
     ISL_HIP(hipGetLastError());

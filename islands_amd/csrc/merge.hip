@@ -30,13 +30,18 @@ __global__ void merge_topk_kernel(uint32_t nlists, uint32_t nq, uint32_t k,
                  cstr = lstride ? lstride : (uint64_t)nq * 4;
   auto ids_of = [&](uint32_t l) { return (const uint64_t*)((const char*)ids0 + l * istr) + (uint64_t)q * k; };
   auto sc_of = [&](uint32_t l) { return (const float*)((const char*)scores0 + l * sstr) + (uint64_t)q * k; };
-  auto cnt_of = [&](uint32_t l) { return *((const uint32_t*)((const char*)counts0 + l * cstr) + q); };
+  // a count of ISL_SHARD_POISON_COUNT marks a list whose producer failed the query (multi-GPU exchange:
+  // a rank whose shard search failed still takes part in the collective, shard.hip): the list counts
+  // as empty here and bit 2 of *flags tells every rank that the batch is not a complete answer
+  auto raw_cnt_of = [&](uint32_t l) { return *((const uint32_t*)((const char*)counts0 + l * cstr) + q); };
+  auto cnt_of = [&](uint32_t l) { const uint32_t c = raw_cnt_of(l); return c == ISL_SHARD_POISON_COUNT ? 0u : c; };
   constexpr uint32_t MAXL = 64;
   uint32_t pos[MAXL];
   uint32_t total = 0;
-  bool sorted = true, has_nan = false;
+  bool sorted = true, has_nan = false, poisoned = false;
   for (uint32_t l = 0; l < nlists; ++l) {
     pos[l] = 0;
+    if (raw_cnt_of(l) == ISL_SHARD_POISON_COUNT) poisoned = true;
     uint32_t c = cnt_of(l);
     if (c > k) c = k;
     total += c;
@@ -48,6 +53,7 @@ __global__ void merge_topk_kernel(uint32_t nlists, uint32_t nq, uint32_t k,
   }
   if (has_nan && total > 1) atomicOr(flags, 1u);
   if (!sorted) atomicOr(flags, 2u);
+  if (poisoned) atomicOr(flags, 4u);
   uint32_t n = 0;
   while (n < top_k) {
     int best = -1;
@@ -157,6 +163,8 @@ static isl_status merge_lists(uint32_t service, uint64_t nlists, uint64_t nq, ui
                          : "Search error: NaN score in merge (the reference panics here)");
   if (flags & 2u)
     return isl::fail(ISL_ERR_INVALID_ARGUMENT, "per-list scores must be ascending");
+  if (flags & 4u)
+    return isl::fail(ISL_ERR_SEARCH, "Search error: a list carries the failed-producer mark (count 0xFFFFFFFF)");
   return ISL_OK;
 }
 

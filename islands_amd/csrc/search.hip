@@ -1301,22 +1301,35 @@ void host_copy_out(const isl::SearchWorkspace& ws, uint64_t nq, uint64_t k, uint
 
 // Runs `body` (the synchronous form of a call, on the claimed lane `ws`) on a host thread; the
 // token's wait joins it.  The thread selects the index's device first (the HIP device is per thread).
+// Thread creation can fail (std::system_error, bad_alloc): nothing may cross the C ABI, so that is an
+// ISL_ERR_DEVICE of the call and the lane goes back through the caller's LaneGuard; `threaded` is set
+// only once the thread object exists.
 template <typename F>
-void start_worker(const isl_index* idx, isl::SearchWorkspace* ws, F body) {
+isl_status start_worker(const isl_index* idx, isl::SearchWorkspace* ws, F body) {
   ws->worker_status = ISL_OK;
+  ws->threaded = false;
+  std::thread* th = nullptr;
+  try {
+    th = new std::thread([idx, ws, body]() {
+      isl_status st = isl::use_device(idx->device);
+      try {  // nothing may leave the thread: an exception here would end the process
+        if (st == ISL_OK) st = body();
+      } catch (const std::exception& e) {
+        st = isl::fail(ISL_ERR_SEARCH, "Search error: %s", e.what());
+      } catch (...) {
+        st = isl::fail(ISL_ERR_SEARCH, "Search error: unknown exception in the call's worker thread");
+      }
+      ws->worker_status = st;
+      ws->worker_error = isl::last_error();
+    });
+  } catch (const std::exception& e) {
+    return isl::fail(ISL_ERR_DEVICE, "the call's worker thread could not be started: %s", e.what());
+  } catch (...) {
+    return isl::fail(ISL_ERR_DEVICE, "the call's worker thread could not be started");
+  }
+  ws->worker = th;
   ws->threaded = true;
-  ws->worker = new std::thread([idx, ws, body]() {
-    isl_status st = isl::use_device(idx->device);
-    try {  // nothing may leave the thread: an exception here would end the process
-      if (st == ISL_OK) st = body();
-    } catch (const std::exception& e) {
-      st = isl::fail(ISL_ERR_SEARCH, "Search error: %s", e.what());
-    } catch (...) {
-      st = isl::fail(ISL_ERR_SEARCH, "Search error: unknown exception in the call's worker thread");
-    }
-    ws->worker_status = st;
-    ws->worker_error = isl::last_error();
-  });
+  return ISL_OK;
 }
 // true when the lane's call ran on a worker: *st = its status, the caller's error record = the worker's
 bool join_worker(isl::SearchWorkspace& ws, isl_status* st) {
@@ -1386,6 +1399,29 @@ isl_status ensure_padded_adjacency(isl_index* idx) {
   idx->d_ell_deg = deg;
   idx->ell_w = W;
   idx->ell_owned = true;
+  return ISL_OK;
+}
+
+// multi-GPU exchange (shard.hip): the queries of call `token` that did not end in QS_OK get
+// ISL_SHARD_POISON_COUNT as their count in the rank's record, so that every rank's merge sees which
+// answers are incomplete.  Enqueued on `stream`, which must already wait for the call's kernels
+// (isl_search_stream_wait).  Calls that run on a worker thread are finished by then (the stream wait
+// joined them), their status array is final as well.
+__global__ void poison_failed_kernel(const uint32_t* __restrict__ status, uint32_t* __restrict__ counts, uint32_t nq) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq && status[i] != QS_OK) counts[i] = ISL_SHARD_POISON_COUNT;
+}
+isl_status poison_failed_queries(const isl_index* idx, uint64_t token, uint32_t* d_counts, uint64_t nq, hipStream_t stream) {
+  const uint32_t* status = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    for (auto& w : idx->ws)
+      if (w.busy && w.token == token) { status = w.status; break; }
+  }
+  if (!status) return fail(ISL_ERR_INVALID_ARGUMENT, "unknown or already completed search token");
+  hipLaunchKernelGGL(poison_failed_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, stream, status, d_counts,
+                     (uint32_t)nq);
+  ISL_HIP(hipGetLastError());
   return ISL_OK;
 }
 
@@ -1515,10 +1551,10 @@ isl_status isl_search_batch_device_async(const isl_index* idx, const float* d_qu
     ISL_TRY(ensure_lane_stream(idx, *ws));
     ISL_HIP(hipEventRecord(ws->ev_in, (hipStream_t)stream));
     ISL_HIP(hipStreamWaitEvent(ws->stream, ws->ev_in, 0));
-    start_worker(idx, ws, [=]() {
+    ISL_TRY(start_worker(idx, ws, [=]() {
       return search_sync(idx, *ws, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count, nullptr,
                          StreamMode::OWN);
-    });
+    }));
   } else
   ISL_TRY(search_enqueue(idx, *ws, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count,
                          (hipStream_t)stream, StreamMode::OWN_AFTER_USER));
@@ -1547,10 +1583,10 @@ isl_status isl_search_batch_async(const isl_index* idx, const float* queries, ui
   LaneGuard guard{idx, ws};
   ISL_TRY(host_stage_in(idx, *ws, queries, nq, d, k));
   if (idx->recompute) {
-    start_worker(idx, ws, [=]() {
+    ISL_TRY(start_worker(idx, ws, [=]() {
       return search_sync(idx, *ws, ws->q_stage, nq, d, k, ef, ws->ids_stage, ws->dist_stage, ws->count_stage, nullptr,
                          StreamMode::OWN);
-    });
+    }));
   } else
   ISL_TRY(search_enqueue(idx, *ws, ws->q_stage, nq, d, k, ef, ws->ids_stage, ws->dist_stage, ws->count_stage,
                          nullptr, StreamMode::OWN));
@@ -1742,10 +1778,10 @@ isl_status isl_search_two_level_batch_device_async(const isl_index* idx, const f
   ISL_HIP(hipEventRecord(ws->ev_in, (hipStream_t)stream));
   ISL_HIP(hipStreamWaitEvent(ws->stream, ws->ev_in, 0));
   const TwoLevelCall tl{rerank_ratio};
-  start_worker(idx, ws, [=]() {
+  ISL_TRY(start_worker(idx, ws, [=]() {
     return search_sync(idx, *ws, d_queries, nq, d, k, ef, d_out_ids, d_out_dist, d_out_count, nullptr, StreamMode::OWN,
                        &tl);
-  });
+  }));
   {
     std::lock_guard<std::mutex> lock(idx->mu);
     ws->token = idx->next_token++;

@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 
 namespace {
 
@@ -76,8 +77,12 @@ static_assert(ISL_SHARD_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size
 
 struct Slot {
   bool busy = false;
+  bool zombie = false;        // the submit failed on this rank: nobody will ask for the result, the slot
+                              // goes back once its exchange has completed (reclaimed by a later submit)
+  bool lost = false;          // its exchange timed out: the collective may still touch the buffers, never reused
   uint64_t handle = 0, token = 0;
   uint64_t nq = 0, k = 0;
+  uint64_t released_at = 0;   // free slots are reused least-recently-released first
   uint8_t* rec = nullptr;    // this rank's record, written in place by the search kernels
   uint8_t* gath = nullptr;   // [world][B]
   uint64_t* ids = nullptr;   // merged answers
@@ -86,8 +91,12 @@ struct Slot {
   uint32_t* cnt = nullptr;
   uint8_t* h_rec = nullptr;  // host transport: pinned mirrors
   uint8_t* h_gath = nullptr;
+  uint32_t* d_flags = nullptr;  // this batch's merge flags (one word of the searcher's array)
+  uint32_t* h_flags = nullptr;  // ... and their pinned mirror, written on the side stream behind the merge
   hipEvent_t done = nullptr;  // behind the merge of the batch in this slot
   bool recorded = false;      // ... once the submit got that far
+  isl_status local_st = ISL_OK;  // why this rank poisoned its record (ISL_OK: it did not)
+  isl::ErrorRecord local_err;
 };
 
 }  // namespace
@@ -106,16 +115,21 @@ struct isl_sharded_searcher {
   uint64_t n_total = 0;
   std::vector<uint64_t> id_base;
   uint64_t* d_base = nullptr;
-  uint32_t* d_flags = nullptr;
+  uint32_t* d_flags = nullptr;   // [depth] one word per slot, cleared on the side stream before the slot's merge
+  uint32_t* h_flags = nullptr;   // [depth] pinned mirrors
+  uint32_t flags_seen = 0;       // OR of the flags of every completed batch (isl_sharded_flags)
+  uint8_t* d_warm = nullptr;     // [16 + 16 * world] the 16-byte status exchange of isl_sharded_prepare
+  uint8_t* h_warm = nullptr;     // pinned, same size
   hipStream_t side = nullptr;
   int32_t depth = 1;
   std::vector<Slot> slots;
   uint64_t cap_nq = 0, cap_k = 0;
-  uint64_t next_slot = 0, next_handle = 1;
-  // staging of the host-buffer entry point
+  uint64_t release_clock = 1, next_handle = 1;
+  // staging of the host-buffer entry point (one such call at a time: host_mu spans the whole call)
   float* d_q = nullptr;
   uint64_t d_q_bytes = 0;
   std::mutex mu;
+  std::mutex host_mu;
 };
 
 namespace {
@@ -130,10 +144,26 @@ void free_slot(Slot& s) {
   s = Slot{};
 }
 
+// a slot is free for a submit when nothing of a batch can still touch it
+bool slot_in_use(const Slot& sl) { return sl.busy || sl.zombie || sl.lost; }
+
+// Slots whose submit failed locally (nobody asks for their result) go back once their exchange has
+// completed; under s->mu.
+void reclaim_zombies(isl_sharded_searcher* s) {
+  for (Slot& sl : s->slots) {
+    if (!sl.zombie) continue;
+    if (sl.recorded && hipEventQuery(sl.done) != hipSuccess) { (void)hipGetLastError(); continue; }
+    if (sl.token) { (void)isl_search_wait(s->idx, sl.token); sl.token = 0; }
+    sl.zombie = false;
+    sl.released_at = s->release_clock++;
+  }
+}
+
 isl_status size_slots(isl_sharded_searcher* s, uint64_t nq, uint64_t k) {
   if (nq <= s->cap_nq && k <= s->cap_k && !s->slots.empty()) return ISL_OK;
+  reclaim_zombies(s);
   for (const Slot& sl : s->slots)
-    if (sl.busy)
+    if (slot_in_use(sl))
       return isl::fail(ISL_ERR_SEARCH, "Search error: a larger batch than isl_sharded_prepare sized the buffers for, "
                        "while batches are in flight");
   const uint64_t cnq = std::max(nq, s->cap_nq), ck = std::max<uint64_t>(std::max(k, s->cap_k), 1);
@@ -141,6 +171,7 @@ isl_status size_slots(isl_sharded_searcher* s, uint64_t nq, uint64_t k) {
   s->slots.assign((size_t)s->depth, Slot{});
   s->cap_nq = s->cap_k = 0;
   const uint64_t B = isl_shard_record_bytes(cnq, ck);
+  size_t i = 0;
   for (Slot& sl : s->slots) {
     ISL_HIP(hipMalloc(&sl.rec, B));
     ISL_HIP(hipMalloc(&sl.gath, B * (uint64_t)s->world));
@@ -154,9 +185,85 @@ isl_status size_slots(isl_sharded_searcher* s, uint64_t nq, uint64_t k) {
       ISL_HIP(hipHostMalloc(&sl.h_gath, B * (uint64_t)s->world));
     }
     ISL_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    sl.d_flags = s->d_flags + i;
+    sl.h_flags = s->h_flags + i;
+    sl.released_at = s->release_clock++;
+    ++i;
   }
   s->cap_nq = cnq;
   s->cap_k = ck;
+  return ISL_OK;
+}
+
+// how long a wait on an exchange may take before the batch is declared lost (a peer that never arrives)
+uint64_t exchange_timeout_ms() {
+  static const uint64_t ms = [] {
+    const char* e = getenv("ISL_SHARD_TIMEOUT_MS");
+    const long long v = e ? atoll(e) : 60000;
+    return (uint64_t)(v > 0 ? v : 60000);
+  }();
+  return ms;
+}
+
+// hipEventSynchronize with a deadline: 0 = completed, 1 = timed out, -1 = a HIP error (in *err)
+int wait_event_bounded(hipEvent_t ev, hipError_t* err) {
+  const auto t0 = std::chrono::steady_clock::now();
+  uint32_t spins = 0;
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) return 0;
+    if (e != hipErrorNotReady) { *err = e; (void)hipGetLastError(); return -1; }
+    (void)hipGetLastError();
+    if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if ((spins & 255u) == 0 &&
+        (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >
+            exchange_timeout_ms())
+      return 1;
+  }
+}
+int wait_stream_bounded(hipStream_t st, hipError_t* err) {
+  const auto t0 = std::chrono::steady_clock::now();
+  uint32_t spins = 0;
+  for (;;) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e == hipSuccess) return 0;
+    if (e != hipErrorNotReady) { *err = e; (void)hipGetLastError(); return -1; }
+    (void)hipGetLastError();
+    if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if ((spins & 255u) == 0 &&
+        (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >
+            exchange_timeout_ms())
+      return 1;
+  }
+}
+
+// the batch's merge flags -> their pinned mirror (a kernel, like the search path's publish: no runtime copy)
+__global__ void publish_flags_kernel(const uint32_t* __restrict__ d_flags, uint32_t* __restrict__ h_flags) {
+  *h_flags = *d_flags;
+}
+// every count of a record = ISL_SHARD_POISON_COUNT: this rank has no answer for the batch
+__global__ void poison_record_kernel(uint32_t* __restrict__ counts, uint32_t nq) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq) counts[i] = ISL_SHARD_POISON_COUNT;
+}
+
+// One all-gather of `bytes` from every rank over the searcher's transport, device buffers, on the side
+// stream (RCCL / single rank: enqueued; host transport: synchronous, through the pinned mirrors).
+isl_status exchange(isl_sharded_searcher* s, const uint8_t* d_send, uint8_t* d_recv, uint8_t* h_send, uint8_t* h_recv,
+                    uint64_t bytes) {
+  if (s->grp && s->grp->comm) {  // (also with a single rank: the communicator the caller set up is used)
+    Rccl* r = nullptr;
+    ISL_TRY(rccl_ready(r));
+    ISL_NCCL(r, r->AllGather(d_send, d_recv, bytes, ncclUint8, s->grp->comm, s->side));
+  } else if (s->world == 1 || !s->grp) {
+    ISL_HIP(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, s->side));
+  } else {
+    ISL_HIP(hipMemcpyAsync(h_send, d_send, bytes, hipMemcpyDeviceToHost, s->side));
+    ISL_HIP(hipStreamSynchronize(s->side));
+    const int32_t rc = s->grp->host_fn(s->grp->host_user, h_send, h_recv, bytes);
+    if (rc != 0) return isl::fail(ISL_ERR_IO, "IO error: the host all-gather callback returned %d", rc);
+    ISL_HIP(hipMemcpyAsync(d_recv, h_recv, bytes * (uint64_t)s->world, hipMemcpyHostToDevice, s->side));
+  }
   return ISL_OK;
 }
 
@@ -264,12 +371,16 @@ isl_status isl_sharded_searcher_new(const isl_index* shard, isl_shard_group* grp
   for (int r = 0; r < s->world; ++r)
     s->id_base[(size_t)r] = id_base ? id_base[r] : n_total * (uint64_t)r / (uint64_t)s->world;
   auto bail = [&](isl_status st) { isl_sharded_searcher_free(s); return st; };
-  if (hipMalloc(&s->d_base, (size_t)s->world * 8) != hipSuccess || hipMalloc(&s->d_flags, 4) != hipSuccess ||
+  const size_t warm = 16 + 16 * (size_t)s->world;
+  if (hipMalloc(&s->d_base, (size_t)s->world * 8) != hipSuccess || hipMalloc(&s->d_flags, (size_t)depth * 4) != hipSuccess ||
+      hipHostMalloc(&s->h_flags, (size_t)depth * 4) != hipSuccess ||
+      hipMalloc(&s->d_warm, warm) != hipSuccess || hipHostMalloc(&s->h_warm, warm) != hipSuccess ||
       hipMemcpy(s->d_base, s->id_base.data(), (size_t)s->world * 8, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemset(s->d_flags, 0, 4) != hipSuccess ||
+      hipMemset(s->d_flags, 0, (size_t)depth * 4) != hipSuccess || hipMemset(s->d_warm, 0, warm) != hipSuccess ||
       hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess)
     return bail(isl::fail(ISL_ERR_DEVICE, "device set-up of the sharded searcher failed: %s",
                           hipGetErrorString(hipGetLastError())));
+  memset(s->h_flags, 0, (size_t)depth * 4);
   *out = s;
   return ISL_OK;
 }
@@ -277,14 +388,22 @@ isl_status isl_sharded_searcher_new(const isl_index* shard, isl_shard_group* grp
 void isl_sharded_searcher_free(isl_sharded_searcher* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  if (s->side) (void)hipStreamSynchronize(s->side);
+  if (s->side) {  // bounded: a peer that never entered a collective must not hang the teardown either
+    hipError_t e = hipSuccess;
+    if (wait_stream_bounded(s->side, &e) == 1)
+      fprintf(stderr, "[isl] sharded searcher freed with an exchange still pending after %llu ms\n",
+              (unsigned long long)exchange_timeout_ms());
+  }
   for (Slot& sl : s->slots) {
     // a batch nobody asked the result of: its search still holds a lane of the index
-    if (sl.busy && sl.token) (void)isl_search_wait(s->idx, sl.token);
-    free_slot(sl);
+    if ((sl.busy || sl.zombie) && sl.token) (void)isl_search_wait(s->idx, sl.token);
+    if (!sl.lost) free_slot(sl);  // (a lost slot's buffers may still be written by a late collective: leaked on purpose)
   }
   if (s->d_base) (void)hipFree(s->d_base);
   if (s->d_flags) (void)hipFree(s->d_flags);
+  if (s->h_flags) (void)hipHostFree(s->h_flags);
+  if (s->d_warm) (void)hipFree(s->d_warm);
+  if (s->h_warm) (void)hipHostFree(s->h_warm);
   if (s->d_q) (void)hipFree(s->d_q);
   if (s->side) (void)hipStreamDestroy(s->side);
   delete s;
@@ -295,17 +414,35 @@ isl_status isl_sharded_prepare(isl_sharded_searcher* s, uint64_t max_nq, uint64_
   if (max_nq == 0) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "max_nq out of range");
   ISL_TRY(isl::use_device(s->device));
   std::lock_guard<std::mutex> lock(s->mu);
-  ISL_TRY(size_slots(s, max_nq, max_k));
-  if (s->idx->num_nodes)
-    ISL_TRY(isl_index_prepare(const_cast<isl_index*>(s->idx), max_nq, max_ef, max_k, s->depth));
-  if (s->grp && s->grp->comm) {
-    // the communicator's first collective sets up its channels: do it here, not in the first batch
-    Rccl* r = nullptr;
-    ISL_TRY(rccl_ready(r));
-    Slot& sl = s->slots[0];
-    ISL_NCCL(r, r->AllGather(sl.rec, sl.gath, 16, ncclUint8, s->grp->comm, s->side));
-    ISL_HIP(hipStreamSynchronize(s->side));
+  // this rank's own set-up; whatever it returns, the collective below is entered
+  isl_status local = size_slots(s, max_nq, max_k);
+  if (local == ISL_OK && s->idx->num_nodes)
+    local = isl_index_prepare(const_cast<isl_index*>(s->idx), max_nq, max_ef, max_k, s->depth);
+  const isl::ErrorRecord keep = isl::last_error();
+  if (!s->grp) return local;
+  // 16 bytes per rank, byte 0 = "my set-up failed".  With RCCL this is also the communicator's first
+  // collective, which sets up its channels: made here, not in the first batch.
+  uint8_t mine[16] = {(uint8_t)(local != ISL_OK ? 1 : 0)};
+  isl_status ex = ISL_OK;
+  if (hipMemcpy(s->d_warm, mine, 16, hipMemcpyHostToDevice) != hipSuccess)
+    ex = isl::fail(ISL_ERR_DEVICE, "hipMemcpy failed: %s", hipGetErrorString(hipGetLastError()));
+  // (entered even then: the device buffer then holds an older outcome, the peers still get their collective)
+  const isl_status ex2 = exchange(s, s->d_warm, s->d_warm + 16, s->h_warm, s->h_warm + 16, 16);
+  if (ex == ISL_OK) ex = ex2;
+  if (ex == ISL_OK) {
+    hipError_t e = hipSuccess;
+    const int w = wait_stream_bounded(s->side, &e);
+    if (w == 1) ex = isl::fail(ISL_ERR_DEVICE, "the set-up exchange of isl_sharded_prepare did not complete within %llu ms "
+                               "(a rank that never called it?)", (unsigned long long)exchange_timeout_ms());
+    else if (w < 0) ex = isl::fail(ISL_ERR_DEVICE, "shard exchange failed: %s", hipGetErrorString(e));
   }
+  if (local != ISL_OK) { isl::last_error() = keep; return local; }
+  ISL_TRY(ex);
+  std::vector<uint8_t> all(16 * (size_t)s->world);
+  ISL_HIP(hipMemcpy(all.data(), s->d_warm + 16, all.size(), hipMemcpyDeviceToHost));
+  for (int r = 0; r < s->world; ++r)
+    if (all[16 * (size_t)r])
+      return isl::fail(ISL_ERR_SEARCH, "Search error: rank %d failed its part of isl_sharded_prepare", r);
   return ISL_OK;
 }
 
@@ -313,53 +450,78 @@ isl_status isl_sharded_submit(isl_sharded_searcher* s, const float* d_queries, u
                               uint64_t k, uint64_t ef, void* stream, uint64_t* handle) {
   if (!s || !handle) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL argument");
   *handle = 0;
+  // Everything that can fail before the collective point is symmetric across ranks by the contract of
+  // this call (every rank submits the same (nq, k) in the same order, with the same depth): argument
+  // checks, buffer sizes, a free slot.
   if (nq == 0 || k == 0) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "nq and k must be positive");
   ISL_TRY(isl::use_device(s->device));
   std::lock_guard<std::mutex> lock(s->mu);
   ISL_TRY(size_slots(s, nq, k));
-  // slots go round in submission order: a completed batch's answers stay untouched until `depth`
-  // further batches have been submitted
-  Slot& sl = s->slots[(size_t)(s->next_slot % (uint64_t)s->depth)];
-  if (sl.busy)
+  reclaim_zombies(s);
+  // any free slot, the one released longest ago first: a completed batch's answers stay untouched until
+  // `depth` further batches have been submitted, whatever order the results were taken in
+  Slot* slp = nullptr;
+  for (Slot& c : s->slots)
+    if (!slot_in_use(c) && (!slp || c.released_at < slp->released_at)) slp = &c;
+  if (!slp)
     return isl::fail(ISL_ERR_SEARCH, "Search error: %d sharded batches already in flight; isl_sharded_result one first",
                      s->depth);
+  Slot& sl = *slp;
   const uint64_t B = isl_shard_record_bytes(nq, k);
-  uint64_t tok = 0;
-  ISL_TRY(isl_search_batch_device_async(s->idx, d_queries, nq, d, k, ef, (uint64_t*)sl.rec, (float*)(sl.rec + nq * k * 8),
-                                        (uint32_t*)(sl.rec + nq * k * 12), stream, &tok));
-  // From here on the batch exists: every path below leaves the slot busy with the token in it, so
-  // that isl_sharded_result (or _free) completes the search and releases its lane.
-  sl.busy = true;
-  sl.token = tok;
+  uint32_t* rec_counts = (uint32_t*)(sl.rec + nq * k * 12);
+  // ---- from here on this rank takes part in the batch's collective, whatever happens to its own search
   sl.nq = nq;
   sl.k = k;
-  sl.handle = s->next_handle++;
+  sl.token = 0;
   sl.recorded = false;
-  s->next_slot++;
+  sl.local_st = ISL_OK;
+  uint64_t tok = 0;
+  isl_status local = isl_search_batch_device_async(s->idx, d_queries, nq, d, k, ef, (uint64_t*)sl.rec,
+                                                   (float*)(sl.rec + nq * k * 8), rec_counts, stream, &tok);
+  sl.token = tok;
+  if (local == ISL_OK) {
+    if (tok) {
+      local = isl_search_stream_wait(s->idx, tok, s->side);
+      // per-query failures (NodeNotFound, scratch exhausted ...): those queries' counts are poisoned, so
+      // that the other ranks' merges see them too
+      if (local == ISL_OK) local = isl::poison_failed_queries(s->idx, tok, rec_counts, nq, s->side);
+    } else {
+      // an empty shard answered at once (counts zeroed on the NULL stream, leann.rs:875-877)
+      if (hipStreamSynchronize(nullptr) != hipSuccess)
+        local = isl::fail(ISL_ERR_DEVICE, "hipStreamSynchronize failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+  }
+  if (local != ISL_OK) {
+    sl.local_st = local;
+    sl.local_err = isl::last_error();
+    // a search that did get enqueued may still write the record: complete it first, then poison
+    if (tok) { (void)isl_search_wait(s->idx, tok); sl.token = 0; }
+    hipLaunchKernelGGL(poison_record_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, s->side, rec_counts,
+                       (uint32_t)nq);
+    (void)hipGetLastError();
+  }
+  isl_status ex = exchange(s, sl.rec, sl.gath, sl.h_rec, sl.h_gath, B);
+  if (ex == ISL_OK && hipMemsetAsync(sl.d_flags, 0, 4, s->side) != hipSuccess)
+    ex = isl::fail(ISL_ERR_DEVICE, "hipMemsetAsync failed: %s", hipGetErrorString(hipGetLastError()));
+  if (ex == ISL_OK)
+    ex = isl_merge_topk_packed_async((uint64_t)s->world, nq, k, sl.gath, B, s->d_base, k, sl.ids, sl.dist, sl.src, sl.cnt,
+                                     sl.d_flags, s->device, s->side);
+  if (ex == ISL_OK) {
+    hipLaunchKernelGGL(publish_flags_kernel, dim3(1), dim3(1), 0, s->side, sl.d_flags, sl.h_flags);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(sl.done, s->side) != hipSuccess)
+      ex = isl::fail(ISL_ERR_DEVICE, "enqueue on the exchange stream failed: %s", hipGetErrorString(hipGetLastError()));
+    else
+      sl.recorded = true;
+  }
+  if (local != ISL_OK || ex != ISL_OK) {
+    // nobody will ask for this batch's result on this rank: the slot goes back behind its exchange
+    sl.zombie = true;
+    if (local != ISL_OK) { isl::last_error() = sl.local_err; return local; }
+    return ex;
+  }
+  sl.busy = true;
+  sl.handle = s->next_handle++;
   *handle = sl.handle;
-  if (tok) {
-    ISL_TRY(isl_search_stream_wait(s->idx, tok, s->side));
-  } else {
-    // an empty shard answered at once (counts zeroed on the NULL stream, leann.rs:875-877)
-    ISL_HIP(hipStreamSynchronize(nullptr));
-  }
-  if (s->grp && s->grp->comm) {  // (also with a single rank: the communicator the caller set up is used)
-    Rccl* r = nullptr;
-    ISL_TRY(rccl_ready(r));
-    ISL_NCCL(r, r->AllGather(sl.rec, sl.gath, B, ncclUint8, s->grp->comm, s->side));
-  } else if (s->world == 1) {
-    ISL_HIP(hipMemcpyAsync(sl.gath, sl.rec, B, hipMemcpyDeviceToDevice, s->side));
-  } else {
-    ISL_HIP(hipMemcpyAsync(sl.h_rec, sl.rec, B, hipMemcpyDeviceToHost, s->side));
-    ISL_HIP(hipStreamSynchronize(s->side));
-    const int32_t rc = s->grp->host_fn(s->grp->host_user, sl.h_rec, sl.h_gath, B);
-    if (rc != 0) return isl::fail(ISL_ERR_IO, "IO error: the host all-gather callback returned %d", rc);
-    ISL_HIP(hipMemcpyAsync(sl.gath, sl.h_gath, B * (uint64_t)s->world, hipMemcpyHostToDevice, s->side));
-  }
-  ISL_TRY(isl_merge_topk_packed_async((uint64_t)s->world, nq, k, sl.gath, B, s->d_base, k, sl.ids, sl.dist, sl.src, sl.cnt,
-                                      s->d_flags, s->device, s->side));
-  ISL_HIP(hipEventRecord(sl.done, s->side));
-  sl.recorded = true;
   return ISL_OK;
 }
 
@@ -380,15 +542,31 @@ isl_status isl_sharded_result(isl_sharded_searcher* s, uint64_t handle, const ui
   // waited for in either case -- the slot must not go back while they still read its buffers
   const isl_status st = sl->token ? isl_search_wait_stats(s->idx, sl->token, stats) : ISL_OK;
   const isl::ErrorRecord keep = isl::last_error();
-  // (the batch's own event: the side stream also carries the exchanges of the batches behind it)
-  const hipError_t e = sl->recorded ? hipEventSynchronize(sl->done) : hipStreamSynchronize(s->side);
+  // (the batch's own event: the side stream also carries the exchanges of the batches behind it);
+  // bounded -- a peer that never enters the collective is an error of this batch, not a hang
+  hipError_t e = hipSuccess;
+  const int w = sl->recorded ? wait_event_bounded(sl->done, &e) : wait_stream_bounded(s->side, &e);
+  uint32_t flags = 0;
   {
     std::lock_guard<std::mutex> lock(s->mu);
     sl->busy = false;
     sl->token = 0;
+    if (w == 1) {
+      sl->lost = true;  // the collective may still complete later and write the slot: never reused
+    } else {
+      sl->released_at = s->release_clock++;
+      if (w == 0) { flags = *sl->h_flags; s->flags_seen |= flags; }
+    }
   }
+  if (w == 1)
+    return isl::fail(ISL_ERR_DEVICE, "the exchange of sharded batch %llu did not complete within %llu ms (a rank that "
+                     "never submitted it?)", (unsigned long long)handle, (unsigned long long)exchange_timeout_ms());
   if (st != ISL_OK) { isl::last_error() = keep; return st; }
-  if (e != hipSuccess) return isl::fail(ISL_ERR_DEVICE, "shard exchange failed: %s", hipGetErrorString(e));
+  if (w < 0) return isl::fail(ISL_ERR_DEVICE, "shard exchange failed: %s", hipGetErrorString(e));
+  if (flags & 4u)
+    return isl::fail(ISL_ERR_SEARCH, "Search error: the shard search of another rank failed for sharded batch %llu "
+                     "(MultiIndexSearcher::search propagates an index's error, search.rs:215)", (unsigned long long)handle);
+  if (flags & 1u) return isl::fail(ISL_ERR_SEARCH, "Search error: NaN score in merge (the reference panics here)");
   if (d_ids) *d_ids = sl->ids;
   if (d_dist) *d_dist = sl->dist;
   if (d_src) *d_src = sl->src;
@@ -399,8 +577,13 @@ isl_status isl_sharded_result(isl_sharded_searcher* s, uint64_t handle, const ui
 isl_status isl_sharded_flags(isl_sharded_searcher* s, uint32_t* flags) {
   if (!s || !flags) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL argument");
   ISL_TRY(isl::use_device(s->device));
-  ISL_HIP(hipStreamSynchronize(s->side));
-  ISL_HIP(hipMemcpy(flags, s->d_flags, 4, hipMemcpyDeviceToHost));
+  hipError_t e = hipSuccess;
+  const int w = wait_stream_bounded(s->side, &e);
+  if (w == 1) return isl::fail(ISL_ERR_DEVICE, "the exchange stream did not drain within %llu ms",
+                               (unsigned long long)exchange_timeout_ms());
+  if (w < 0) return isl::fail(ISL_ERR_DEVICE, "shard exchange failed: %s", hipGetErrorString(e));
+  std::lock_guard<std::mutex> lock(s->mu);
+  *flags = s->flags_seen;
   return ISL_OK;
 }
 
@@ -412,34 +595,27 @@ isl_status isl_sharded_search_batch(isl_sharded_searcher* s, const float* querie
   if (!queries || !out_count || (k && (!out_ids || !out_dist))) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
   if (k == 0) { memset(out_count, 0, nq * 4); return ISL_OK; }
   ISL_TRY(isl::use_device(s->device));
-  {
-    std::lock_guard<std::mutex> lock(s->mu);
-    const uint64_t bytes = nq * d * 4;
-    if (s->d_q_bytes < bytes) {
-      if (s->d_q) (void)hipFree(s->d_q);
-      s->d_q = nullptr;
-      s->d_q_bytes = 0;
-      ISL_HIP(hipMalloc(&s->d_q, bytes));
-      s->d_q_bytes = bytes;
-    }
+  // one host-buffer call at a time per searcher: the staging buffer is reallocated, filled, searched
+  // from and its answers copied out under this lock (two threads would otherwise overwrite each
+  // other's queries or free the buffer under a search in flight)
+  std::lock_guard<std::mutex> host_lock(s->host_mu);
+  const uint64_t bytes = nq * d * 4;
+  if (s->d_q_bytes < bytes) {
+    if (s->d_q) (void)hipFree(s->d_q);
+    s->d_q = nullptr;
+    s->d_q_bytes = 0;
+    ISL_HIP(hipMalloc(&s->d_q, bytes));
+    s->d_q_bytes = bytes;
   }
-  ISL_HIP(hipMemcpy(s->d_q, queries, nq * d * 4, hipMemcpyHostToDevice));
+  ISL_HIP(hipMemcpy(s->d_q, queries, bytes, hipMemcpyHostToDevice));
   uint64_t h = 0;
-  const isl_status sub = isl_sharded_submit(s, s->d_q, nq, d, k, ef, nullptr, &h);
-  const isl::ErrorRecord keep = isl::last_error();
+  ISL_TRY(isl_sharded_submit(s, s->d_q, nq, d, k, ef, nullptr, &h));
   const uint64_t *ids = nullptr; const float* dist = nullptr; const uint32_t *src = nullptr, *cnt = nullptr;
-  if (h) {
-    const isl_status st = isl_sharded_result(s, h, &ids, &dist, &src, &cnt, nullptr);
-    if (sub == ISL_OK) ISL_TRY(st);
-  }
-  if (sub != ISL_OK) { isl::last_error() = keep; return sub; }
+  ISL_TRY(isl_sharded_result(s, h, &ids, &dist, &src, &cnt, nullptr));  // (this batch's own flags are checked there)
   ISL_HIP(hipMemcpy(out_ids, ids, nq * k * 8, hipMemcpyDeviceToHost));
   ISL_HIP(hipMemcpy(out_dist, dist, nq * k * 4, hipMemcpyDeviceToHost));
   if (out_src) ISL_HIP(hipMemcpy(out_src, src, nq * k * 4, hipMemcpyDeviceToHost));
   ISL_HIP(hipMemcpy(out_count, cnt, nq * 4, hipMemcpyDeviceToHost));
-  uint32_t flags = 0;
-  ISL_HIP(hipMemcpy(&flags, s->d_flags, 4, hipMemcpyDeviceToHost));
-  if (flags & 1u) return isl::fail(ISL_ERR_SEARCH, "Search error: NaN score in merge (the reference panics here)");
   return ISL_OK;
 }
 

@@ -38,6 +38,9 @@ def record_bytes(nq: int, k: int) -> int:
     return (nq * k * 12 + nq * 4 + 15) // 16 * 16
 
 
+POISON_COUNT_I32 = -1  # ISL_SHARD_POISON_COUNT (0xFFFFFFFF) as the int32 the count views hold
+
+
 def record_views(buf: torch.Tensor, nq: int, k: int):
     """(ids [.., nq, k] int64, dist [.., nq, k] f32, count [.., nq] int32) views of a uint8 record
     buffer [B] or of gathered records [world, B]."""
@@ -163,10 +166,12 @@ class ShardedSearcher:
         self.shard_group = None
         self._shapes = {}
         if index is not None:
-            if transport is None:
-                transport = "rccl" if (self.world == 1 or self.backend == "nccl") else "host"
+            # a single rank needs no group (the header's "world == 1 needs no group"): RCCL is loaded and a
+            # communicator made only when the caller asks for transport="rccl" explicitly
+            if transport is None and self.world > 1:
+                transport = "rccl" if self.backend == "nccl" else "host"
             dev_index = self.device.index or 0
-            if self.world > 1 or transport == "rccl":
+            if transport is not None:
                 self.shard_group = ShardGroup(dev_index, group, transport)
             _check(_ffi.lib().isl_sharded_searcher_new(
                 index._h, self.shard_group._h if self.shard_group else None, n_total,
@@ -192,16 +197,32 @@ class ShardedSearcher:
                 self._h, q.ctypes.data_as(C.c_void_p), nq, d, k, ef, ids.ctypes.data_as(C.c_void_p),
                 dd.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)))
             return ids, dd, src, cnt
-        ids, dd, cnt = self.local_search(queries, k, ef)
-        nq = ids.shape[0]
+        # A rank whose shard search fails still takes part in the exchange, with a record whose counts are
+        # ISL_SHARD_POISON_COUNT; every rank then fails the batch (MultiIndexSearcher::search propagates an
+        # index's error, search.rs:215) and nobody is left inside the collective -- the rule of shard.hip.
+        nq = int(queries.shape[0])
+        local_error = None
+        try:
+            ids, dd, cnt = self.local_search(queries, k, ef)
+        except Exception as e:  # noqa: BLE001 -- whatever the local search raised is this rank's error
+            local_error = e
         B = record_bytes(nq, k)
         assert B == int(_ffi.lib().isl_shard_record_bytes(nq, k))
         rec = torch.zeros(B, dtype=torch.uint8, device=self.device)
         r_ids, r_dd, r_cnt = record_views(rec, nq, k)
-        r_ids.copy_(ids); r_dd.copy_(dd); r_cnt.copy_(cnt)
+        if local_error is None:
+            r_ids.copy_(ids); r_dd.copy_(dd); r_cnt.copy_(cnt)
+        else:
+            r_cnt.fill_(POISON_COUNT_I32)
         gathered = torch.zeros((self.world, B), dtype=torch.uint8, device=self.device)
         self._all_gather_records(gathered, rec)  # the one exchange step of the path
+        if local_error is not None:
+            raise local_error
         g_ids, g_dd, g_cnt = record_views(gathered, nq, k)
+        failed = (g_cnt == POISON_COUNT_I32).any(dim=1)
+        if bool(failed.any()):
+            raise CoreError(11, "Search error: the shard search of rank(s) "
+                                f"{torch.nonzero(failed).flatten().tolist()} failed for this batch")
         return self.merge(g_ids, g_dd, g_cnt, self.id_base, k)
 
     # ------------------------------------------------------------------ GPU path (C ABI)
@@ -245,6 +266,8 @@ class ShardedSearcher:
             raise CoreError(11, "Search error: NaN score in merge (the reference panics here)")
         if f.value & 2:
             raise CoreError(14, "per-list scores must be ascending")
+        if f.value & 4:
+            raise CoreError(11, "Search error: a rank failed one of the batches")
 
     def close(self):
         if self._h:

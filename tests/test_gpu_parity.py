@@ -475,6 +475,44 @@ def test_bruteforce_topk(orc):
     assert few[2].tolist() == [4, 4]
 
 
+def _check_topk(ids, dist, row, k):
+    """ids / dist = the k smallest of `row` by (distance, id): distances to 2e-6 (another launch shape of
+    the GEMM may round differently), ascending, ids exact wherever the order is not within that rounding,
+    equal distances in id order."""
+    n = row.shape[0]
+    order = np.lexsort((np.arange(n), row))[:k + 1]
+    assert np.abs(dist - row[order[:k]]).max() < 2e-6
+    assert np.all(np.diff(dist) >= 0)
+    assert len(set(ids.tolist())) == k and np.abs(row[ids.astype(np.int64)] - dist).max() < 2e-6
+    ex = row[order]
+    for j in range(k):
+        lo_ok = j == 0 or ex[j] - ex[j - 1] > 1e-5
+        hi_ok = j + 1 >= ex.size or ex[j + 1] - ex[j] > 1e-5
+        if lo_ok and hi_ok:
+            assert ids[j] == order[j]
+    for j in range(k - 1):
+        if dist[j] == dist[j + 1]:
+            assert ids[j] < ids[j + 1]
+
+
+def test_bruteforce_topk_scans_ragged_blocks_and_ties(orc):
+    # column counts that are not a multiple of the scan's 4-wide loads or of its 256-column step, a
+    # block boundary inside the row set (nq large enough to split the rows into chunks) and rows that
+    # repeat (equal distances: the smaller id wins)
+    d, k = 32, 12
+    for n, nq in ((1, 3), (3, 3), (255, 5), (257, 5), (1030, 9), (70001, 4099)):
+        rows = clustered_vectors(n, d, 21)
+        if n > 600:
+            rows[500:520] = rows[100:120]  # duplicates
+        q = clustered_vectors(nq, d, 22)
+        ids, dist, cnt = ia.bruteforce_topk(ia.DistanceMetric.Cosine, q, rows, k)
+        kk = min(k, n)
+        assert (cnt == kk).all()
+        dm = ia.distance_matrix(ia.DistanceMetric.Cosine, q[:64], rows)  # the same GEMM (another launch shape)
+        for i in range(min(nq, 64)):
+            _check_topk(ids[i, :kk], dist[i, :kk], dm[i], kk)
+
+
 # ---------------------------------------------------------------- bf16 row storage
 def to_bf16_bits(a):
     u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
@@ -483,6 +521,20 @@ def to_bf16_bits(a):
 
 def widen(bits):
     return (bits.astype(np.uint32) << 16).view(np.float32)
+
+
+def test_bruteforce_topk_bf16_is_exact_under_the_bf16_gemm():
+    d, k = 128, 11
+    for n, nq in ((300, 7), (5000, 33), (66000, 4100)):
+        rows = to_bf16_bits(clustered_vectors(n, d, 31))
+        q = to_bf16_bits(clustered_vectors(nq, d, 32))
+        ids, dist, cnt = ia.bruteforce_topk_bf16(ia.DistanceMetric.Cosine, q, rows, k)
+        assert (cnt == k).all()
+        dm = ia.distance_matrix_bf16(ia.DistanceMetric.Cosine, q[:48], rows)
+        for i in range(min(nq, 48)):
+            _check_topk(ids[i], dist[i], dm[i], k)
+    with pytest.raises(ia.CoreError):
+        ia.bruteforce_topk_bf16(ia.DistanceMetric.Cosine, q[:, :100], rows[:, :100], k)  # d % 64
 
 
 @pytest.mark.parametrize("metric", METRICS)

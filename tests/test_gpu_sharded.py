@@ -85,6 +85,80 @@ def _worker(rank, world, port, n_total, d, k, ef, out_path):
     dist.destroy_process_group()
 
 
+def _failing_worker(rank, world, port, n_total, d, k, ef, out_path):
+    """Batch 1: rank 1's shard search fails (queries of the wrong dimension on that rank only); batch 2:
+    a query of rank 1's shard ends in NodeNotFound (an edge to a node without a row); batches 0 and 3
+    are ordinary.  No rank may block, every rank must see batches 1 and 2 fail and 0 and 3 succeed."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["ISL_SHARD_TIMEOUT_MS"] = "20000"
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc, x, shards, qs = _shards(n_total, d, world)
+    import islands_amd as ia
+    from islands_amd.sharded import ShardedSearcher
+
+    torch.cuda.set_device(0)
+    lo, xs, csr = shards[rank]
+    g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels, entry_point=0,
+                    num_nodes=csr.num_nodes, degree_counts=csr.degree_counts)
+    idx = ia.LeannIndex.from_csr(g, dimension=d).upload(0)
+    idx.set_embeddings(xs)
+    s = ShardedSearcher(n_total, index=idx, device="cuda:0", depth=3)
+    s.prepare(qs[0].shape[0], k, ef)
+    log = []
+
+    def run(q):
+        try:
+            h = s.submit(q, k, ef)
+        except ia.CoreError as e:
+            return ("submit", e.kind)
+        try:
+            ids, dd, src, cnt = s.result(h)
+        except ia.CoreError as e:
+            return ("result", e.kind)
+        return ("ok", ids.cpu().numpy().copy().tolist())
+
+    dq = [torch.from_numpy(q).cuda() for q in qs]
+    log.append(run(dq[0]))
+    # batch 1: the wrong dimension on rank 1 only (same nq, k: the exchange's record has the same size)
+    bad = torch.zeros((dq[1].shape[0], d + 8), device="cuda:0") if rank == 1 else dq[1]
+    log.append(run(bad))
+    # batch 2: rank 1 loses the rows of the upper half of its shard -> its queries end in NodeNotFound
+    if rank == 1:
+        idx.set_embeddings(xs[: xs.shape[0] // 2])
+    log.append(run(dq[2]))
+    if rank == 1:
+        idx.set_embeddings(xs)
+    log.append(run(dq[3]))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, log)
+    if rank == 0:
+        torch.save(gathered, out_path)
+    s.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_a_failing_rank_fails_the_batch_on_every_rank_and_nobody_hangs(tmp_path):
+    world, n_total, d, k, ef = 2, 3000, 32, 7, 40
+    out = str(tmp_path / "log.pt")
+    mp.spawn(_failing_worker, args=(world, _free_port(), n_total, d, k, ef, out), nprocs=world, join=True)
+    logs = torch.load(out, weights_only=False)
+    r0, r1 = logs
+    # ordinary batches before and after: answered, identically on both ranks
+    assert r0[0][0] == "ok" and r1[0] == r0[0]
+    assert r0[3][0] == "ok" and r1[3] == r0[3]
+    # batch 1: rank 1 reports its own error at submit (DimensionMismatch), rank 0 a SearchError at result
+    assert r1[1] == ("submit", "DimensionMismatch"), r1[1]
+    assert r0[1] == ("result", "SearchError"), r0[1]
+    # batch 2: rank 1's own NodeNotFound at result, rank 0 a SearchError at result
+    assert r1[2] == ("result", "NodeNotFound"), r1[2]
+    assert r0[2] == ("result", "SearchError"), r0[2]
+
+
 @pytest.mark.timeout(600)
 def test_two_ranks_one_card_equal_multi_index_searcher(tmp_path):
     world, n_total, d, k, ef = 2, 3000, 32, 7, 40

@@ -109,3 +109,60 @@ def test_two_rank_gather_and_merge(tmp_path):
         # global ids index the unsharded matrix: distances must match a direct evaluation
         for gid, dd in zip(ids.tolist(), sc.tolist()):
             assert orc.distance(orc.COSINE, q[qi], x[gid])[1] == np.float32(dd)
+
+
+def _poison_worker(rank, world, port, n_total, d, k, ef, out_path):
+    """Batch 0 ordinary, batch 1: rank 1's local search raises, batch 2 ordinary again."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc, x, shards, q = _setup_shards(n_total, d, world)
+    import islands_amd as ia
+    from islands_amd.sharded import POISON_COUNT_I32, ShardedSearcher, record_bytes, record_views
+
+    lo, xs, csr = shards[rank]
+    calls = {"n": 0}
+
+    def local_search(queries, k, ef):
+        calls["n"] += 1
+        if rank == 1 and calls["n"] == 2:
+            raise ia.CoreError(5, "Node not found: 12345", node=12345)
+        ids, dd, cnt, _ = orc.leann_search_batch(csr, xs, queries, k, ef)
+        return (torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(dd), torch.from_numpy(cnt.astype(np.int32)))
+
+    seen = []
+
+    def merge(g_ids, g_dist, g_cnt, id_base, k):
+        seen.append(g_cnt.clone())
+        return [g_ids[:, qi, :].tolist() for qi in range(g_ids.shape[1])]
+
+    s = ShardedSearcher(n_total, local_search, merge)
+    log = []
+    for b in range(3):
+        try:
+            res = s.search_batch(q, k, ef)
+            log.append(("ok", res))
+        except ia.CoreError as e:
+            log.append(("error", e.kind, str(e)))
+    # the poisoned record never reaches the merge, and the count views read it as POISON_COUNT_I32
+    assert len(seen) == 2 and all(bool((c != POISON_COUNT_I32).all()) for c in seen)
+    rec = torch.zeros(record_bytes(4, k), dtype=torch.uint8)
+    record_views(rec, 4, k)[2].fill_(POISON_COUNT_I32)
+    assert rec[4 * k * 12:4 * k * 12 + 16].tolist() == [255] * 16  # == ISL_SHARD_POISON_COUNT, little endian
+    gathered = [None] * world
+    dist.all_gather_object(gathered, log)
+    if rank == 0:
+        torch.save(gathered, out_path)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_a_failing_rank_poisons_its_record_and_every_rank_fails_the_batch(tmp_path):
+    world, n_total, d, k, ef = 2, 600, 16, 5, 24
+    out = str(tmp_path / "log.pt")
+    mp.spawn(_poison_worker, args=(world, _free_port(), n_total, d, k, ef, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out, weights_only=False)
+    assert r0[0][0] == "ok" and r1[0] == r0[0]          # before: answered, the same on both ranks
+    assert r1[1][:2] == ("error", "NodeNotFound")        # the failing rank: its own error
+    assert r0[1][:2] == ("error", "SearchError") and "rank(s) [1]" in r0[1][2]  # the other: the peer's failure
+    assert r0[2][0] == "ok" and r1[2] == r0[2]          # after: the next batch succeeds, nobody hung

@@ -146,6 +146,100 @@ def brute_force_topk_native(x: torch.Tensor, q: torch.Tensor, k: int, metric: in
     return ids, dd
 
 
+def brute_force_topk_bf16_native(x16: torch.Tensor, q16: torch.Tensor, k: int, metric: int = 0):
+    """Exact top-k under the library's bf16 distance GEMM (isl_bruteforce_topk_bf16), device buffers."""
+    import ctypes as C
+
+    from islands_amd import _check, _ffi
+    nq = q16.shape[0]
+    assert x16.dtype == torch.bfloat16 and q16.dtype == torch.bfloat16
+    x16, q16 = x16.contiguous(), q16.contiguous()
+    ids = torch.zeros((nq, k), dtype=torch.int64, device=x16.device)
+    dd = torch.zeros((nq, k), dtype=torch.float32, device=x16.device)
+    cnt = torch.zeros(nq, dtype=torch.int32, device=x16.device)
+    torch.cuda.synchronize(x16.device)
+    _check(_ffi.lib().isl_bruteforce_topk_bf16(
+        metric, C.c_void_p(q16.data_ptr()), nq, C.c_void_p(x16.data_ptr()), x16.shape[0], x16.shape[1], k,
+        C.c_void_p(ids.data_ptr()), C.c_void_p(dd.data_ptr()), C.c_void_p(cnt.data_ptr()), 1,
+        x16.device.index or 0, None))
+    return ids, dd
+
+
+@torch.no_grad()
+def build_knn_graph(x: torch.Tensor, k: int = 30, m0: int = 60, block: int = 16384, bf16_above: int = 2_000_000,
+                    progress=None):
+    """A graph the harness did not tailor: every node's k exact nearest neighbours (cosine) by the
+    library's own brute force -- float32 MFMA blocks up to `bf16_above` rows, the bf16 distance GEMM
+    beyond (1.5e17 flops at 10M x 768) --, plus the reverse edges, rows truncated to m0 (own neighbours
+    first, nearest first; then reverse edges, nearest first).  Entry point = the medoid (the row
+    nearest to the mean of all rows), as NSG / Vamana take it.  No hierarchy, no diversification.
+    Returns (offsets int64 [n+1], neighbours int32 [nnz], entry)."""
+    dev = x.device
+    n, d = x.shape
+    use16 = n > bf16_above and d % 64 == 0
+    x16 = x.to(torch.bfloat16) if use16 else None
+    nb = torch.empty((n, k), dtype=torch.int64, device=dev)
+    nd = torch.empty((n, k), dtype=torch.float32, device=dev)
+    self_ids = torch.arange(n, device=dev)
+    for s0 in range(0, n, block):
+        s1 = min(n, s0 + block)
+        if use16:
+            ii, dd = brute_force_topk_bf16_native(x16, x16[s0:s1], k + 1)
+        else:
+            ii, dd = brute_force_topk_native(x, x[s0:s1], k + 1)
+        # drop the node itself (first unless an exact duplicate row ties with it)
+        own = ii == self_ids[s0:s1, None]
+        has = own.any(1)
+        drop = torch.where(has, own.to(torch.int64).argmax(1), torch.full_like(has, k, dtype=torch.int64))
+        keep = torch.arange(k + 1, device=dev)[None, :] != drop[:, None]
+        nb[s0:s1] = ii[keep].view(-1, k)
+        nd[s0:s1] = dd[keep].view(-1, k)
+        if progress and (s0 // block) % 16 == 0:
+            progress(f"kNN lists of rows [{s0}, {s1}) of {n}")
+    del x16
+    src = self_ids[:, None].expand(n, k).reshape(-1)
+    dst = nb.reshape(-1)
+    dist = nd.reshape(-1)
+    # forward edges rank before reverse edges, nearest first inside each class
+    f_key = dist.double()
+    r_key = dist.double() + 16.0
+    a_src, a_dst, a_key = torch.cat([src, dst]), torch.cat([dst, src]), torch.cat([f_key, r_key])
+    o = torch.argsort(a_key, stable=True)
+    a_src, a_dst, a_key = a_src[o], a_dst[o], a_key[o]
+    o = torch.argsort(a_src * (1 << 32) + a_dst, stable=True)  # (src, dst) groups, best key first inside
+    a_src, a_dst, a_key = a_src[o], a_dst[o], a_key[o]
+    first = torch.ones_like(a_src, dtype=torch.bool)
+    first[1:] = (a_src[1:] != a_src[:-1]) | (a_dst[1:] != a_dst[:-1])
+    a_src, a_dst, a_key = a_src[first], a_dst[first], a_key[first]
+    o = torch.argsort(a_key, stable=True)
+    a_src, a_dst = a_src[o], a_dst[o]
+    o = torch.argsort(a_src, stable=True)  # rows, best key first
+    a_src, a_dst = a_src[o], a_dst[o]
+    start = torch.ones_like(a_src, dtype=torch.bool)
+    start[1:] = a_src[1:] != a_src[:-1]
+    seg_start = torch.nonzero(start).squeeze(1)
+    seg_id = torch.cumsum(start.to(torch.int64), 0) - 1
+    within = torch.arange(a_src.numel(), device=dev) - seg_start[seg_id]
+    ok = within < m0
+    a_src, a_dst = a_src[ok], a_dst[ok]
+    deg = torch.bincount(a_src, minlength=n)
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    offsets[1:] = torch.cumsum(deg, 0)
+    mean = torch.zeros(d, dtype=torch.float64, device=dev)
+    for s0 in range(0, n, 1 << 18):
+        mean += x[s0:s0 + (1 << 18)].double().sum(0)
+    mean = (mean / n).float()
+    best, entry = -3.0, 0
+    mn = mean / mean.norm().clamp_min(1e-30)
+    for s0 in range(0, n, 1 << 18):
+        xb = x[s0:s0 + (1 << 18)]
+        sim = (xb @ mn) / xb.norm(dim=1).clamp_min(1e-30)
+        v, i = sim.max(0)
+        if float(v) > best:
+            best, entry = float(v), s0 + int(i)
+    return offsets, a_dst.to(torch.int32), entry
+
+
 def recall_at_k(found_ids: torch.Tensor, found_cnt: torch.Tensor, truth_ids: torch.Tensor) -> float:
     k = truth_ids.shape[1]
     f = found_ids[:, :k].to(torch.int64)
