@@ -174,7 +174,8 @@ def measure_traffic(args):
              "--warmup", "1", "--pipeline", "1", "--nodes", str(args.nodes), "--dim", str(args.dim), "--nq",
              str(args.nq), "--k", str(args.k), "--ef", str(args.ef), "--per-cluster", str(args.per_cluster),
              "--row-dtype", args.row_dtype, "--dataset", args.dataset, "--distinct-batches",
-             str(args.distinct_batches), "--graph", args.graph, "--no-cpu-baseline", "--no-host-path", "--no-traffic"]
+             str(args.distinct_batches), "--graph", args.graph, "--no-cpu-baseline", "--no-host-path", "--no-traffic"] + \
+        (["--distinct-leaves"] if args.distinct_leaves else [])
     cmd = [rp, "--pmc", "FETCH_SIZE", "--kernel-include-regex", "leann_search_fast", "-d", out, "-o", "p",
            "--output-format", "csv", "--"] + child
     env = dict(os.environ, TMPDIR="/tmp")
@@ -281,6 +282,11 @@ def main():
                          "exact nearest neighbours by the library's own brute force + reverse edges, truncated to 60 "
                          "-- no hierarchy, no diversification; product: the library's isl_index_build, i.e. the "
                          "reference's LeannIndex::build rule (leann.rs:560-833), batch mode")
+    ap.add_argument("--distinct-leaves", action="store_true",
+                    help="measurement aid (dataset G): consecutive queries come from different leaf clusters -- with "
+                         "N / per-cluster leaves, any that many consecutive queries share no neighbourhood, so rows "
+                         "fetched by one query in flight are not re-used by another (what part of the rate is "
+                         "cross-query cache reuse: DESIGN section 4)")
     ap.add_argument("--ef-sweep", default="256,512",
                     help="when recall@10 at --ef misses 0.95: the larger ef values tried (one after the other, "
                          "until one reaches it); empty = none")
@@ -393,7 +399,7 @@ def main():
             nb_h = raw[91 + 8 * n_off:91 + 8 * n_off + 8 * n_nb].view(np.uint64)
             offsets = torch.from_numpy(off_h.astype(np.int64)).to(dev)
             neighbours = torch.from_numpy(nb_h.astype(np.int32)).to(dev)
-            entry = idx.entry_point()
+            entry = idx.entry_point
             del raw
         else:
             offsets, neighbours, entry = synth.build_graph(x, m0=60)
@@ -435,7 +441,8 @@ def main():
             if args.dataset == "U":
                 q = synth.make_uniform(nq, d, 43 + qoff, device=dev)
             else:
-                q = synth.make_rows(N, d, qoff, nq, per_cluster=args.per_cluster, device=dev, query=True)
+                q = synth.make_rows(N, d, qoff, nq, per_cluster=args.per_cluster, device=dev, query=True,
+                                    distinct_leaves=args.distinct_leaves)
             if args.row_dtype == "bf16":  # config 5: the queries are bf16 values too (their exact f32 images)
                 q = q.to(torch.bfloat16).to(torch.float32)
             qsets.append(q.contiguous())
@@ -612,6 +619,7 @@ def main():
                             f"query batch {nq}, k={k}, ef={ef}, cosine",
                 "nodes": N, "dim": d, "query_batch": nq, "k": k, "ef": ef,
                 "graph": args.graph, "graph_build_s": round(graph_build_s, 1),
+                "distinct_leaves": bool(args.distinct_leaves),
                 "rehearsed_shard": ({"shard": args.rehearse_shard, "rows": [lo, hi]} if args.rehearse_shard else None),
                 "parallelism": ("single" if world == 1 else
                                 (f"shard{world}: node-id ranges, RCCL all-gather + top-k merge"

@@ -558,6 +558,16 @@ isl_status isl_hnsw_last_stats(const isl_hnsw* h, isl_search_stats* out);
 isl_status isl_distance_matrix_bf16(int32_t metric, const uint16_t* queries, uint64_t nq, const uint16_t* rows,
                                     uint64_t n, uint64_t d, float* out, int32_t mem, int32_t device,
                                     void* stream);
+/* Sum of squares of every row of a bf16 matrix (of the exact float32 images), as the cosine / Euclidean
+ * epilogues of isl_distance_matrix_bf16 take it; out [n] f32. */
+isl_status isl_row_sumsq_bf16(const uint16_t* rows, uint64_t n, uint64_t d, float* out, int32_t mem, int32_t device,
+                              void* stream);
+/* isl_distance_matrix_bf16 for callers that keep the rows (or the queries) resident across calls:
+ * q_sumsq [nq] / row_sumsq [n] = isl_row_sumsq_bf16 of them, in the matrices' memory space, computed
+ * once instead of per call (NULL = computed here).  Same outputs, bit for bit. */
+isl_status isl_distance_matrix_bf16_norms(int32_t metric, const uint16_t* queries, uint64_t nq, const uint16_t* rows,
+                                          uint64_t n, uint64_t d, const float* q_sumsq, const float* row_sumsq,
+                                          float* out, int32_t mem, int32_t device, void* stream);
 /* isl_bruteforce_topk over bf16 rows and queries: blocks of isl_distance_matrix_bf16 + the same running
  * top-k (ties towards the smaller id), exact under the bf16 GEMM's distances.  Ground truth and exact
  * kNN lists at sizes where the float32 GEMM would take tens of minutes (10M x 10M x 768). */

@@ -210,6 +210,43 @@ extern "C" {
 isl_status isl_distance_matrix_bf16(int32_t metric, const uint16_t* queries, uint64_t nq, const uint16_t* rows,
                                     uint64_t n, uint64_t d, float* out, int32_t mem, int32_t device,
                                     void* stream) {
+  return isl_distance_matrix_bf16_norms(metric, queries, nq, rows, n, d, nullptr, nullptr, out, mem, device, stream);
+}
+
+// sum of squares of every row of a bf16 matrix (its exact float32 images), in the order the distance
+// epilogues take it: what isl_distance_matrix_bf16 computes per call, for callers that keep the rows
+// resident and ask for their distances to many query batches (config 5: 26 batches x 153 row blocks)
+isl_status isl_row_sumsq_bf16(const uint16_t* rows, uint64_t n, uint64_t d, float* out, int32_t mem, int32_t device,
+                              void* stream) {
+  if (n == 0) return ISL_OK;
+  if (!rows || !out) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
+  if (d == 0) return isl::fail(ISL_ERR_EMPTY_COLLECTION, "Empty vector collection");
+  ISL_TRY(isl::use_device(device));
+  hipStream_t st = (hipStream_t)stream;
+  Staged s;
+  const uint16_t* dr = rows;
+  float* dout = out;
+  if (mem == ISL_MEM_HOST) {
+    uint16_t* b = (uint16_t*)s.alloc(n * d * 2);
+    dout = (float*)s.alloc(n * 4);
+    if (!b || !dout) return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed");
+    ISL_HIP(hipMemcpyAsync(b, rows, n * d * 2, hipMemcpyHostToDevice, st));
+    dr = b;
+  }
+  for (uint64_t r0 = 0; r0 < n; r0 += 0x7FFFFFFCull)  // grid.x limit (four rows per workgroup)
+    hipLaunchKernelGGL(sumsq_rows_bf16_kernel, dim3((uint32_t)((std::min<uint64_t>(n - r0, 0x7FFFFFFCull) + 3) / 4)), dim3(256),
+                       0, st, dr + r0 * d, std::min<uint64_t>(n - r0, 0x7FFFFFFCull), (uint32_t)d, dout + r0);
+  ISL_HIP(hipGetLastError());
+  if (mem == ISL_MEM_HOST) ISL_HIP(hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, st));
+  ISL_HIP(hipStreamSynchronize(st));
+  return ISL_OK;
+}
+
+// q_sumsq / row_sumsq: isl_row_sumsq_bf16 of the queries / rows (same memory space as the matrices), or
+// NULL = computed here.  The outputs do not depend on who computed them (same kernel, same order).
+isl_status isl_distance_matrix_bf16_norms(int32_t metric, const uint16_t* queries, uint64_t nq, const uint16_t* rows,
+                                          uint64_t n, uint64_t d, const float* q_sumsq, const float* row_sumsq,
+                                          float* out, int32_t mem, int32_t device, void* stream) {
   if (nq == 0 || n == 0) return ISL_OK;
   if (!queries || !rows || !out) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
   if (d == 0) return isl::fail(ISL_ERR_EMPTY_COLLECTION, "Empty vector collection");
@@ -233,12 +270,20 @@ isl_status isl_distance_matrix_bf16(int32_t metric, const uint16_t* queries, uin
   }
   if (((uintptr_t)dq & 15) || ((uintptr_t)dr & 15))
     return isl::fail(ISL_ERR_INVALID_ARGUMENT, "bf16 matrices must be 16-byte aligned");
-  float* qn = (float*)s.alloc(nq * 4);
-  float* rn = (float*)s.alloc(n * 4);
-  if (!qn || !rn) return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed");
+  const float *qn = nullptr, *rn = nullptr;
   if (metric != ISL_METRIC_DOT) {  // (the dot epilogue reads no norms)
-    hipLaunchKernelGGL(sumsq_rows_bf16_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, dq, nq, (uint32_t)d, qn);
-    hipLaunchKernelGGL(sumsq_rows_bf16_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, dr, n, (uint32_t)d, rn);
+    float* qbuf = (q_sumsq && mem == ISL_MEM_DEVICE) ? nullptr : (float*)s.alloc(nq * 4);
+    float* rbuf = (row_sumsq && mem == ISL_MEM_DEVICE) ? nullptr : (float*)s.alloc(n * 4);
+    if ((!qbuf && !(q_sumsq && mem == ISL_MEM_DEVICE)) || (!rbuf && !(row_sumsq && mem == ISL_MEM_DEVICE)))
+      return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed");
+    if (q_sumsq && mem == ISL_MEM_HOST) ISL_HIP(hipMemcpyAsync(qbuf, q_sumsq, nq * 4, hipMemcpyHostToDevice, st));
+    else if (!q_sumsq)
+      hipLaunchKernelGGL(sumsq_rows_bf16_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, dq, nq, (uint32_t)d, qbuf);
+    if (row_sumsq && mem == ISL_MEM_HOST) ISL_HIP(hipMemcpyAsync(rbuf, row_sumsq, n * 4, hipMemcpyHostToDevice, st));
+    else if (!row_sumsq)
+      hipLaunchKernelGGL(sumsq_rows_bf16_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, dr, n, (uint32_t)d, rbuf);
+    qn = qbuf ? qbuf : q_sumsq;
+    rn = rbuf ? rbuf : row_sumsq;
   }
   ISL_TRY(launch_distance_gemm_bf16(metric, dq, dr, qn, rn, dout, nq, n, d, n, st));
   if (mem == ISL_MEM_HOST) ISL_HIP(hipMemcpyAsync(out, dout, nq * n * 4, hipMemcpyDeviceToHost, st));

@@ -471,6 +471,21 @@ isl_status check_ids_flag(isl_encoder* e, hipStream_t st) {
 }  // namespace
 
 namespace isl {
+// Batch sizes the model passes of encoder_embed_nodes run at full waves of GEMM tiles: *chunk = the
+// sequences of one pass, *quantum = the largest batch whose narrowest Linear (hidden -> hidden, 256 x 256
+// tiles, one workgroup per CU) still fits one wave of tiles over the chip.  (h = 768, L = 64, 256 CUs:
+// 85 row tiles x 3 column tiles = 255 tiles -> 340 sequences; two such batches fill two waves, and so on.)
+void encoder_batch_quantum(const isl_encoder* e, uint32_t L, uint32_t* quantum, uint32_t* chunk) {
+  *quantum = 0;
+  *chunk = 2048;
+  if (!e || !L) return;
+  const uint32_t ncu = (uint32_t)device_cu_count(e->device);
+  const uint32_t col_tiles = (e->cfg.hidden + 255) / 256;
+  const uint32_t row_tiles = ncu / std::max<uint32_t>(col_tiles, 1);
+  const uint64_t q = (uint64_t)row_tiles * 256 / L;
+  if (q >= 16 && q <= *chunk) *quantum = (uint32_t)q;
+}
+
 isl_status encoder_embed_nodes(isl_encoder* e, const uint16_t* d_tokens, const uint16_t* d_lens,
                                uint32_t L, const uint32_t* d_node_ids, uint64_t n, int normalize,
                                float* d_rows, uint64_t stride, hipStream_t st, const uint32_t* d_out_rows) {

@@ -36,6 +36,8 @@ namespace isl {
 // d_rows + d_node_ids[b] * stride.  Sequences are padded to L: masked keys contribute exact
 // zeros, so the result does not depend on the padded length.
 // d_out_rows (device, may be NULL = the node ids): embedding b goes to d_rows + d_out_rows[b] * stride.
+// batch sizes at which the passes of encoder_embed_nodes run whole waves of GEMM tiles (0 = unknown)
+void encoder_batch_quantum(const isl_encoder* e, uint32_t L, uint32_t* quantum, uint32_t* chunk);
 isl_status encoder_embed_nodes(isl_encoder* e, const uint16_t* d_tokens, const uint16_t* d_lens,
                                uint32_t L, const uint32_t* d_node_ids, uint64_t n, int normalize,
                                float* d_rows, uint64_t stride, hipStream_t st,

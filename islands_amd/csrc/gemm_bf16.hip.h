@@ -7,6 +7,7 @@
 // column) l % 32 and the 8 consecutive k values 8 * (l / 32) .. + 7 of each 16-wide k step.
 #pragma once
 
+#include <algorithm>
 #include <type_traits>
 
 #include "common.hpp"
@@ -570,6 +571,61 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_ph8(const __bf16* __restrict
     const uint64_t n = n0 + wn + j * 16 + (lane & 15);
     bvs[j] = (bias && n < N) ? bias[n] : 0.0f;
   }
+  if constexpr ((VAR & 4) != 0 && !C16 && ACT >= EPI_COSINE) {
+    // Round 4: the distance epilogues go through a wave-private patch of the (now idle) K-tile buffers --
+    // 8 rows x 64 columns, pitch 288 bytes: the four row groups of an MFMA block land on different banks --
+    // ds_write_b32 of the finished values, then ds_read_b128 and ONE global_store_dwordx4 per four whole
+    // 256-byte rows: 32 store instructions per lane instead of 128 of four 64-byte row segments each.
+    // Same values, bit for bit (the launcher takes this form when ldc % 4 == 0 and C is 16-byte aligned).
+    // Measured with it (tools/microbench/gemm_bf16_ph8.hip, profiles/r04_gemm_bf16_ph8p_variants.log): as part
+    // of a persistent workgroup per CU that also stages the next tile's first K-tiles under its epilogue
+    // (gemm_tn_bf16_ph8p below) the cosine kernel gains 2.5 % over the per-element epilogue, but the
+    // persistent structure itself loses 5 % to this one-tile kernel, and non-temporal stores another 2-4 %.
+    constexpr uint32_t EP_PITCH = 72;
+    float* const ep = reinterpret_cast<float*>(lds) + wave * (8 * EP_PITCH);
+    const uint32_t g4 = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {  // rows 4 g4 + 2 h + {0, 1} of the 16-row block -> patch rows 2 g4 + {0, 1}
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int r = 2 * h + rr;
+          const uint64_t m = m0 + wm + i * 16 + 4 * g4 + r;
+          const float rm = (ROWNORM && m < M) ? R[m] : 0.0f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v = acc4[i][j][r];
+            if (ACT == EPI_COSINE) v = epi_cosine(v, rm, bvs[j]);
+            else if (ACT == EPI_DOT) v = -v;
+            else v = epi_euclidean(v, rm, bvs[j]);
+            ep[(g4 * 2 + rr) * EP_PITCH + j * 16 + c] = v;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const uint32_t lrow = 4 * t + g4;  // patch row: group lrow / 2, row rr = lrow % 2
+          const uint64_t m = m0 + wm + i * 16 + 4 * (lrow >> 1) + 2 * h + (lrow & 1u);
+          const uint64_t n = n0 + wn + c * 4;
+          const floatx4_t v = *reinterpret_cast<const floatx4_t*>(&ep[lrow * EP_PITCH + c * 4]);
+          if (m < M) {
+            float* out = C + m * ldc + n;
+            if (n + 3 < N) {
+              *reinterpret_cast<floatx4_t*>(out) = v;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < N) out[e] = v[e];
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -585,6 +641,293 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_ph8(const __bf16* __restrict
     }
 }
 
+// ---- the eight-phase kernel as ONE persistent workgroup per CU (round 4) ----
+// gemm_tn_bf16_ph8 pays, per 256 x 256 tile: a prologue (K-tile 0 fetched with nothing to compute), and an
+// epilogue of 128 global_store_dword per lane -- four 64-byte row segments per instruction -- with the
+// matrix cores idle: 0.12 ms of a 1.8 ms call at 4096 x 65536 x 4096.  Here a workgroup walks its tiles
+// (virtual block ids blockIdx.x, + gridDim.x, ...: the same XCD-aware tile order as the one-tile kernel):
+//   * the K loop runs on across the tile boundary: the phases of a tile's last two K-tiles stage the
+//     NEXT tile's K-tiles 0 and 1 (the slots they take are the ones K-tiles nk and nk + 1 would have
+//     taken; buffer parity counts K-tiles globally), which land during the epilogue -- no prologue after
+//     the first tile, and the phase-4 wait stays the counted vmcnt(6) (the epilogue's stores are older
+//     than the six loads it leaves outstanding, loads return in order); the one-barrier stagger of waves
+//     4..7 is taken up at every tile's start and given back before its epilogue;
+//   * the epilogue goes through a wave-private LDS patch (8 rows x 64 columns, pitch 288 bytes: the four
+//     row groups of an MFMA block land on different banks): ds_write_b32 of the finished values, then
+//     ds_read_b128 and ONE global_store_dwordx4 per four whole 256-byte rows -- 32 store instructions per
+//     lane instead of 128.
+// MEASURED (profiles/r04_gemm_bf16_ph8p_variants.log, 4096 x 65536 x 4096, rounds interleaved with the one-tile
+// kernel on one card): dot epilogue 1199 TFLOP/s against 1255 for gemm_tn_bf16_ph8, cosine 1145 against
+// 1138; with this kernel's per-element epilogue 1191 / 1118 -- so the LDS-transposed epilogue is worth 0.7 % /
+// 2.5 %, the persistent structure itself costs 5 % (static tile striding instead of the dispatcher's
+// first-free-CU order, 251 registers against 229), and non-temporal result stores cost another 2-4 %.  The
+// library therefore keeps the one-tile kernel and takes only the epilogue (gemm_tn_bf16_ph8, VAR & 4);
+// this kernel stays for the micro-benchmark (ISL_GEMM_PERSIST=1 selects it in the library).
+// Same accumulation order, same epilogue arithmetic: every output bit equals gemm_tn_bf16_ph8's
+// (tools/microbench/gemm_bf16_ph8.hip compares all of them).  Needs K >= 128, ldc % 4 == 0, C 16-byte
+// aligned, float32 output.  VAR (micro-benchmark only): bit 0 = non-temporal result stores,
+// bit 1 = the one-tile kernel's per-element epilogue.
+template <int ACT, bool RES, int VAR = 0>
+__global__ __launch_bounds__(512) void gemm_tn_bf16_ph8p(const __bf16* __restrict__ A, const __bf16* __restrict__ W,
+                                                         const float* __restrict__ bias, const float* __restrict__ R,
+                                                         float* __restrict__ C, uint32_t M, uint32_t N, uint32_t K,
+                                                         uint32_t ntn, uint64_t ldc, uint32_t ntiles) {
+  constexpr uint32_t TM = 256, TN = 256, HT = 16384, KT = 4 * HT;
+  constexpr uint32_t EP_PITCH = 72;  // floats per patch row (288 bytes: consecutive row pairs are 16 banks apart)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // [2][KT] | 8 waves x [8][EP_PITCH] floats
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* const ep = reinterpret_cast<float*>(lds + 2 * KT) + wave * (8 * EP_PITCH);
+  const uint32_t G = gridDim.x;
+  const uint32_t ntm = ntiles / ntn;
+  auto tile_origin = [&](uint32_t vb, uint32_t& m0, uint32_t& n0) {
+    const uint32_t q8 = ntiles / 8, r8 = ntiles % 8, xcd = vb % 8;
+    const uint32_t wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + vb / 8;
+    constexpr uint32_t GM = 8;
+    const uint32_t group = wgid / (GM * ntn), in_group = wgid % (GM * ntn);
+    const uint32_t gm = ntm - group * GM < GM ? ntm - group * GM : GM;
+    m0 = (group * GM + in_group % gm) * TM;
+    n0 = (in_group / gm) * TN;
+  };
+  const uint32_t wr = wave >> 2, wc = wave & 3;
+  const uint32_t wm = wr * 128, wn = wc * 64;
+  typedef float floatx4_t __attribute__((ext_vector_type(4)));
+  floatx4_t acc4[8][4];
+  // staging source of piece i (= 0, 1) of half-tile t of the tile at (m0, n0): see gemm_tn_bf16_ph8
+  // Staging source of piece i (= 0, 1) of half-tile t of the tile at (m0, n0), as an element offset from
+  // the tile's operand panel (A + m0 K or W + n0 K: wave-uniform bases, so that the pieces are eight
+  // 32-bit offsets instead of eight pointers); rows past M / N are clamped to the last one (their
+  // products are never stored).  `tid_` = threadIdx.x: the look-ahead into the next tile passes an
+  // opaque copy of it, so that its offsets are computed where they are used -- two K-tiles per tile --
+  // instead of being hoisted out of the K loop as live registers.
+  auto piece_off = [&](int t, int i, uint32_t m0, uint32_t n0, uint32_t tid_) -> uint32_t {
+    const uint32_t chunk = 512u * i + tid_, r = chunk >> 3, c = (chunk & 7u) ^ ((r >> 1) & 7u);
+    if (t < 2) {
+      const uint32_t row = m0 + (r >> 6) * 128u + t * 64u + (r & 63u);
+      return ((row < M ? row : M - 1) - m0) * K + c * 8u;
+    }
+    const uint32_t col = n0 + (r >> 5) * 64u + (t - 2) * 32u + (r & 31u);
+    return ((col < N ? col : N - 1) - n0) * K + c * 8u;
+  };
+  uint32_t vb = blockIdx.x;
+  uint32_t m0, n0, m1 = 0, n1 = 0;
+  tile_origin(vb, m0, n0);
+  bool has_next = vb + G < ntiles;
+  if (has_next) tile_origin(vb + G, m1, n1);
+  uint32_t soff[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) soff[t][i] = piece_off(t, i, m0, n0, tid);
+  const uint32_t nk = K / HBK;
+  uint32_t par = 0;  // parity of this tile's K-tile 0 in the global count of K-tiles
+  // K-tile `sl` of the current tile (sl < nk) or, past its end, K-tile sl - nk of the next one
+  auto stage = [&](auto tt, uint32_t sl) {
+    constexpr int t = decltype(tt)::value;
+    unsigned char* dst = lds + ((par + sl) & 1u) * KT + t * HT + wave * 1024u;
+    const __bf16 *p0, *p1;
+    if (sl < nk) {
+      const __bf16* base = (t < 2 ? A + (uint64_t)m0 * K : W + (uint64_t)n0 * K) + (uint64_t)sl * HBK;
+      p0 = base + soff[t][0];
+      p1 = base + soff[t][1];
+    } else {
+      uint32_t tid_ = tid;
+      asm volatile("" : "+v"(tid_));
+      const __bf16* base = (t < 2 ? A + (uint64_t)m1 * K : W + (uint64_t)n1 * K) + (uint64_t)(sl - nk) * HBK;
+      p0 = base + piece_off(t, 0, m1, n1, tid_);
+      p1 = base + piece_off(t, 1, m1, n1, tid_);
+    }
+    __builtin_amdgcn_global_load_lds((isl_glb_void*)p0, (isl_lds_void*)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((isl_glb_void*)p1, (isl_lds_void*)(dst + 8192u), 16, 0, 0);
+  };
+  using T_A0 = std::integral_constant<int, 0>; using T_A1 = std::integral_constant<int, 1>;
+  using T_B0 = std::integral_constant<int, 2>; using T_B1 = std::integral_constant<int, 3>;
+  const uint32_t g = lane >> 4, c16 = lane & 15, sw = c16 >> 1;
+  const uint32_t aoff0 = (wr * 64u + c16) * 128u + (((0u + g) ^ sw) << 4), aoff1 = (wr * 64u + c16) * 128u + (((4u + g) ^ sw) << 4);
+  const uint32_t boff0 = (wc * 32u + c16) * 128u + (((0u + g) ^ sw) << 4), boff1 = (wc * 32u + c16) * 128u + (((4u + g) ^ sw) << 4);
+  bf16x8 fa[4][2];
+  bf16x8 fb0[2][2], fb1[2][2];
+  auto read_a = [&](const unsigned char* img) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[i][0] = *reinterpret_cast<const bf16x8*>(img + aoff0 + i * 2048u);
+      fa[i][1] = *reinterpret_cast<const bf16x8*>(img + aoff1 + i * 2048u);
+    }
+  };
+  auto read_b = [&](bf16x8 (&fb)[2][2], const unsigned char* img) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      fb[j][0] = *reinterpret_cast<const bf16x8*>(img + boff0 + j * 2048u);
+      fb[j][1] = *reinterpret_cast<const bf16x8*>(img + boff1 + j * 2048u);
+    }
+  };
+  auto quadrant = [&](auto ai_, auto bj_, const bf16x8 (&fb)[2][2]) {
+    constexpr int ai = decltype(ai_)::value, bj = decltype(bj_)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s32 = 0; s32 < 2; ++s32)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc4[4 * ai + i][2 * bj + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][s32], fb[j][s32], acc4[4 * ai + i][2 * bj + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  auto barrier = [] {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto reads_done = [] {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // prologue (first tile only): K-tile 0 whole, then the three half-tiles of K-tile 1 that phases 2-4 stage
+  stage(T_A0{}, 0); stage(T_B0{}, 0); stage(T_B1{}, 0); stage(T_A1{}, 0);
+  stage(T_B0{}, 1); stage(T_A0{}, 1); stage(T_B1{}, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  barrier();               // every wave's pieces of K-tile 0 have landed
+  constexpr bool ROWNORM = ACT == EPI_COSINE || ACT == EPI_EUCLIDEAN;
+  auto value = [&](uint64_t m, uint64_t n, float bv, float rm, float v) -> float {
+    if (ACT <= 2) {
+      v += bv;
+      if (ACT == 1) v = gelu_erf_f(v);
+      if (ACT == 2) v = gelu_tanh_f(v);
+      if (RES) v += R[m * N + n];
+    } else if (ACT == EPI_COSINE) {
+      v = epi_cosine(v, rm, bv);
+    } else if (ACT == EPI_DOT) {
+      v = -v;
+    } else if (ACT == EPI_EUCLIDEAN) {
+      v = epi_euclidean(v, rm, bv);
+    }
+    return v;
+  };
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc4[i][j][r] = 0.0f;
+    if (wr == 1) barrier();  // waves 4..7 run one barrier behind through the tile's K loop
+    for (uint32_t s = 0; s < nk; ++s) {
+      const unsigned char* cur = lds + ((par + s) & 1u) * KT;
+      // phase 1: quadrant (0, 0)
+      read_b(fb0, cur + 2 * HT);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(cur);
+      if (s + 1 < nk || has_next) stage(T_A1{}, s + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the four B0 reads are back: its slot is restaged next phase
+      barrier();
+      reads_done();
+      quadrant(I0{}, I0{}, fb0);
+      barrier();
+      // phase 2: quadrant (0, 1)
+      const bool ahead2 = s + 2 < nk || has_next;
+      read_b(fb1, cur + 3 * HT);
+      if (ahead2) stage(T_B0{}, s + 2);
+      barrier();
+      reads_done();
+      quadrant(I0{}, I1{}, fb1);
+      barrier();
+      // phase 3: quadrant (1, 1)
+      read_a(cur + HT);
+      if (ahead2) stage(T_A0{}, s + 2);
+      barrier();
+      reads_done();
+      quadrant(I1{}, I1{}, fb1);
+      barrier();
+      // phase 4: quadrant (1, 0); the K-tile's one wait
+      if (ahead2) {
+        stage(T_B1{}, s + 2);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else if (s + 1 < nk) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      barrier();
+      quadrant(I1{}, I0{}, fb0);
+      barrier();
+    }
+    // ---- epilogue of the tile at (m0, n0): all eight waves together (the barrier waves 4..7 took at the
+    // tile's start; staggered, each half of the workgroup would sit out the other half's epilogue)
+    if (wr == 0) barrier();
+    float bvs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t n = (uint64_t)n0 + wn + j * 16 + (lane & 15);
+      bvs[j] = (bias && n < N) ? bias[n] : 0.0f;
+    }
+    if constexpr ((VAR & 2) != 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint64_t m = (uint64_t)m0 + wm + i * 16 + 4 * (lane >> 4) + r;
+          if (m >= M) continue;
+          const float rm = ROWNORM ? R[m] : 0.0f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint64_t n = (uint64_t)n0 + wn + j * 16 + (lane & 15);
+            if (n < N) C[(uint64_t)m * ldc + n] = value(m, n, bvs[j], rm, acc4[i][j][r]);
+          }
+        }
+    } else {
+      const uint32_t g4 = lane >> 4, c = lane & 15;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // rows 4 g4 + 2 h + {0, 1} of the 16-row block -> patch rows 2 g4 + {0, 1}
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * h + rr;
+            const uint64_t m = (uint64_t)m0 + wm + i * 16 + 4 * g4 + r;
+            const float rm = (ROWNORM && m < M) ? R[m] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint64_t n = (uint64_t)n0 + wn + j * 16 + c;
+              ep[(g4 * 2 + rr) * EP_PITCH + j * 16 + c] = (m < M && n < N) ? value(m, n, bvs[j], rm, acc4[i][j][r]) : 0.0f;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const uint32_t lrow = 4 * t + g4;  // patch row: group lrow / 2, row rr = lrow % 2
+            const uint64_t m = (uint64_t)m0 + wm + i * 16 + 4 * (lrow >> 1) + 2 * h + (lrow & 1u);
+            const uint64_t n = (uint64_t)n0 + wn + c * 4;
+            const floatx4_t v = *reinterpret_cast<const floatx4_t*>(&ep[lrow * EP_PITCH + c * 4]);
+            if (m < M) {
+              float* out = C + m * ldc + n;
+              if (n + 3 < N) {
+                if constexpr ((VAR & 1) != 0) __builtin_nontemporal_store(v, reinterpret_cast<floatx4_t*>(out));
+                else *reinterpret_cast<floatx4_t*>(out) = v;
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (n + e < N) out[e] = v[e];
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("" ::: "memory");
+        }
+    }
+    if (!has_next) break;
+    par = (par + nk) & 1u;
+    vb += G;
+    m0 = m1;
+    n0 = n1;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) soff[t][i] = piece_off(t, i, m0, n0, tid);
+    has_next = vb + G < ntiles;
+    if (has_next) tile_origin(vb + G, m1, n1);
+  }
+}
+
 // Picks the tile by the size of the problem: the 256 x 256 tile needs enough tiles to fill the chip.
 template <int ACT, bool RES, bool C16>
 void launch_gemm_bf16_dma(const __bf16* A, const __bf16* W, const float* bias, const float* R, void* C,
@@ -595,6 +938,46 @@ void launch_gemm_bf16_dma(const __bf16* A, const __bf16* W, const float* bias, c
   // the 256 x 256 tile runs on the eight-phase schedule (gemm_tn_bf16_ph8: same outputs bit for bit, 4-5 %
   // faster on 4096 x 65536 x 4096, tools/microbench/gemm_bf16_ph8.hip); ISL_GEMM_PH8=0 keeps round 2's loop
   static const bool ph8 = [] { const char* e = getenv("ISL_GEMM_PH8"); return !e || atoi(e) != 0; }();
+  // ... and as one persistent workgroup per CU with the LDS-transposed epilogue (gemm_tn_bf16_ph8p, round 4):
+  // float32 outputs only; ISL_GEMM_PERSIST=0 keeps the one-tile kernel
+  // (measured slower than the one-tile kernel, see gemm_tn_bf16_ph8p: off unless ISL_GEMM_PERSIST=1)
+  static const bool persist = [] { const char* e = getenv("ISL_GEMM_PERSIST"); return e && atoi(e) != 0; }();
+  if constexpr (!C16) {
+    if (use_big && ph8 && persist && K >= 2 * HBK && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 && big < 0x7FFFFFFFull) {
+      static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n > 0 ? n : 256;
+      }();
+      auto kern = gemm_tn_bf16_ph8p<ACT, RES>;
+      constexpr size_t lds = 2 * (256 + 256) * HBK * 2 + 8 * 8 * 72 * 4;
+      static const bool once = [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return true;
+      }();
+      (void)once;
+      const uint32_t grid = (uint32_t)std::min<uint64_t>(big, (uint64_t)ncu);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, W, bias, R, (float*)C, (uint32_t)M, (uint32_t)N,
+                         (uint32_t)K, (uint32_t)((N + 255) / 256), ldc, (uint32_t)big);
+      return;
+    }
+  }
+  if constexpr (!C16 && ACT >= EPI_COSINE) {
+    // distance epilogues: rows stored whole through the LDS patch (gemm_tn_bf16_ph8, VAR & 4); ISL_GEMM_EPT=0: A/B
+    static const bool ept = [] { const char* e = getenv("ISL_GEMM_EPT"); return !e || atoi(e) != 0; }();
+    if (use_big && ph8 && ept && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0) {
+      auto kern = gemm_tn_bf16_ph8<ACT, RES, C16, 4>;
+      constexpr size_t lds = 2 * (256 + 256) * HBK * 2;
+      static const bool once = [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return true;
+      }();
+      (void)once;
+      hipLaunchKernelGGL(kern, dim3((uint32_t)big), dim3(512), lds, st, A, W, bias, R, C, (uint32_t)M, (uint32_t)N,
+                         (uint32_t)K, (uint32_t)((N + 255) / 256), ldc);
+      return;
+    }
+  }
   if (use_big && ph8) {
     auto kern = gemm_tn_bf16_ph8<ACT, RES, C16>;
     constexpr size_t lds = 2 * (256 + 256) * HBK * 2;

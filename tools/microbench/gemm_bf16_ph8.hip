@@ -16,6 +16,29 @@ static const float* g_rn = nullptr;
 static const float* g_qn = nullptr;
 constexpr size_t kLds = 2 * (256 + 256) * HBK * 2;
 
+// the persistent form (gemm_tn_bf16_ph8p): one workgroup per CU walks the tiles
+template <int EPI, int VAR = 0>
+static float run_p(const __bf16* A, const __bf16* W, float* C, uint32_t M, uint32_t N, uint32_t K, int reps) {
+  const uint32_t ntn = (N + 255) / 256, ntiles = ((M + 255) / 256) * ntn;
+  constexpr size_t lds = kLds + 8 * 8 * 72 * 4;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  auto kern = gemm_tn_bf16_ph8p<EPI, false, VAR>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  auto launch = [&] {
+    hipLaunchKernelGGL(kern, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, 0, A, W, g_rn, g_qn, C, M, N, K, ntn, (uint64_t)N, ntiles);
+  };
+  launch();
+  (void)hipEventRecord(e0);
+  for (int r = 0; r < reps; ++r) launch();
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms / reps;
+}
+
 template <int EPI, bool PH8, int VAR = 0>
 static float run(const __bf16* A, const __bf16* W, float* C, uint32_t M, uint32_t N, uint32_t K, int reps) {
   const uint32_t ntn = (N + 255) / 256, ntiles = ((M + 255) / 256) * ntn;
@@ -77,7 +100,8 @@ int main(int argc, char** argv) {
   const int reps = argc > 4 ? atoi(argv[4]) : 40;
   // edge shapes first (ragged last tiles, one K-tile, two, an odd number): correctness only
   {
-    const uint32_t shapes[][3] = {{300, 1000, 64}, {257, 513, 128}, {256, 256, 192}, {1000, 300, 448}, {512, 768, 4096}};
+    const uint32_t shapes[][3] = {{300, 1000, 64}, {257, 513, 128}, {256, 256, 192}, {1000, 300, 448}, {512, 768, 4096},
+                                  {257, 516, 128}, {2100, 70000, 192}, {4096, 66048, 128}, {3000, 70004, 320}};
     for (auto& sh : shapes) {
       const uint32_t m = sh[0], n = sh[1], k = sh[2];
       __bf16 *a, *w; float *c0, *c1, *rn, *qn;
@@ -97,6 +121,18 @@ int main(int argc, char** argv) {
       (void)run<EPI_COSINE, true>(a, w, c1, m, n, k, 1);
       const hipError_t e = hipDeviceSynchronize();
       printf("shape %u x %u x %u: %llu differing elements (%s)\n", m, n, k, differing(c0, c1, (uint64_t)m * n), hipGetErrorString(e));
+      if (n % 4 == 0) {
+        (void)hipMemset(c1, 0xFF, (size_t)m * n * 4);
+        (void)run<EPI_COSINE, true, 4>(a, w, c1, m, n, k, 1);
+        const hipError_t e3 = hipDeviceSynchronize();
+        printf("   8-phase kernel, LDS-transposed epilogue: %llu differing elements (%s)\n", differing(c0, c1, (uint64_t)m * n), hipGetErrorString(e3));
+      }
+      if (k >= 128 && n % 4 == 0) {
+        (void)hipMemset(c1, 0xFF, (size_t)m * n * 4);
+        (void)run_p<EPI_COSINE>(a, w, c1, m, n, k, 1);
+        const hipError_t e2 = hipDeviceSynchronize();
+        printf("   persistent kernel: %llu differing elements (%s)\n", differing(c0, c1, (uint64_t)m * n), hipGetErrorString(e2));
+      }
       (void)hipFree(a); (void)hipFree(w); (void)hipFree(c0); (void)hipFree(c1); (void)hipFree(rn); (void)hipFree(qn);
     }
   }
@@ -125,9 +161,35 @@ int main(int argc, char** argv) {
     printf("M=%u N=%u K=%u round %d: dot epilogue: 8-wave DMA %.3f ms %.1f TF | 8-phase %.3f ms %.1f TF || cosine: %.3f ms %.1f TF | %.3f ms %.1f TF\n",
            M, N, K, round, t0, fl / t0 / 1e9, t1, fl / t1 / 1e9, t2, fl / t2 / 1e9, t3, fl / t3 / 1e9);
     printf("   8-phase, dot: no setprio %.1f TF | static priority for waves 4..7 only %.1f TF\n", fl / v1 / 1e9, fl / v3 / 1e9);
+    const float p0 = run_p<EPI_DOT>(A, W, C1, M, N, K, reps), p1 = run_p<EPI_DOT, 1>(A, W, C1, M, N, K, reps), p2 = run_p<EPI_DOT, 2>(A, W, C1, M, N, K, reps);
+    const float p3 = run_p<EPI_COSINE>(A, W, C1, M, N, K, reps), p4 = run_p<EPI_COSINE, 1>(A, W, C1, M, N, K, reps), p5 = run_p<EPI_COSINE, 2>(A, W, C1, M, N, K, reps);
+    const float e0 = run<EPI_DOT, true, 4>(A, W, C1, M, N, K, reps), e1 = run<EPI_COSINE, true, 4>(A, W, C1, M, N, K, reps);
+    printf("   8-phase with the LDS-transposed epilogue: dot %.3f ms %.1f TF | cosine %.3f ms %.1f TF\n", e0, fl / e0 / 1e9, e1, fl / e1 / 1e9);
+    printf("   persistent: dot %.3f ms %.1f TF (non-temporal stores %.1f, per-element epilogue %.1f) | cosine %.3f ms %.1f TF (non-temporal stores %.1f, per-element epilogue %.1f)\n",
+           p0, fl / p0 / 1e9, fl / p1 / 1e9, fl / p2 / 1e9, p3, fl / p3 / 1e9, fl / p4 / 1e9, fl / p5 / 1e9);
     fflush(stdout);
   }
+  (void)run<EPI_COSINE, false>(A, W, C0, M, N, K, 1);
+  (void)run<EPI_COSINE, true>(A, W, C1, M, N, K, 1);
   printf("cosine outputs, differing elements of %llu: %llu\n", (unsigned long long)M * N, differing(C0, C1, (uint64_t)M * N));
+  (void)hipMemset(C1, 0xFF, (size_t)M * N * 4);
+  (void)run<EPI_COSINE, true, 4>(A, W, C1, M, N, K, 1);
+  printf("cosine outputs of the 8-phase kernel with the LDS-transposed epilogue, differing elements: %llu\n", differing(C0, C1, (uint64_t)M * N));
+  (void)hipMemset(C1, 0xFF, (size_t)M * N * 4);
+  (void)run_p<EPI_COSINE>(A, W, C1, M, N, K, 1);
+  printf("cosine outputs of the persistent kernel, differing elements: %llu\n", differing(C0, C1, (uint64_t)M * N));
+  (void)hipMemset(C1, 0xFF, (size_t)M * N * 4);
+  (void)run_p<EPI_DOT>(A, W, C1, M, N, K, 1);
+  (void)run<EPI_DOT, false>(A, W, C0, M, N, K, 1);
+  printf("dot outputs of the persistent kernel, differing elements: %llu\n", differing(C0, C1, (uint64_t)M * N));
+  {
+    unsigned long long badp = 0;
+    for (int it = 0; it < 20; ++it) {
+      (void)run_p<EPI_DOT>(A, W, C1, M, N, K, 1);
+      badp += differing(C0, C1, (uint64_t)M * N);
+    }
+    printf("race screen, 20 further runs of the persistent kernel: %llu differing elements in all\n", badp);
+  }
   (void)run<EPI_DOT, false>(A, W, C0, M, N, K, 1);
   (void)run<EPI_DOT, true>(A, W, C1, M, N, K, 1);
   printf("dot outputs, differing elements: %llu\n", differing(C0, C1, (uint64_t)M * N));

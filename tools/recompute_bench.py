@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--warm", action="store_true",
                     help="afterwards, with keep_rows = 1 (the row cache survives the call): a first batch, a second batch "
                          "of other queries, and the first batch again")
+    ap.add_argument("--quantum-ab", action="store_true",
+                    help="run the searches twice: with every miss of a round encoded at once (ISL_RECOMPUTE_QUANTUM=0, "
+                         "rounds 1-3's behaviour) and with the rounds' encoder batches in whole waves of GEMM tiles")
     ap.add_argument("--check-in-memory", action="store_true",
                     help="also run the batch over the in-memory provider holding the same embeddings and compare bits")
     args = ap.parse_args()
@@ -258,6 +261,20 @@ def main():
         log(f"{label}: ef={ef} ratio={tl_ratio}: recall {res['recall_at_10']}, {dt:.1f}s, {res['encoded_nodes_per_query']} nodes/query")
         return res
 
+    if args.quantum_ab:
+        import os
+        for label, env in (("every miss at once", "0"), ("whole tile waves", None), ("every miss at once", "0"),
+                           ("whole tile waves", None)):
+            if env is None:
+                os.environ.pop("ISL_RECOMPUTE_QUANTUM", None)
+            else:
+                os.environ["ISL_RECOMPUTE_QUANTUM"] = env
+            if pq is not None:
+                run(f"two_level, encoder batches: {label}", qh, tih, ef_tl, ratio, check=True)
+            else:
+                run(f"plain, encoder batches: {label}", qh, tih, efs[0], 0.0, check=args.check_in_memory)
+        os.environ.pop("ISL_RECOMPUTE_QUANTUM", None)
+        return
     if pq is None:
         for ef in efs:  # round 2's behaviour: the ef values in turn, stopping at the first that reaches 0.95
             r = run("plain", qh, tih, ef, 0.0, check=args.check_in_memory and ef == args.ef)

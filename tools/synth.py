@@ -61,9 +61,13 @@ def _centres(n_total: int, d: int, per_cluster: int, seed: int, device) -> torch
 
 
 def make_rows(n_total: int, d: int, start: int, count: int, seed: int = 42,
-              per_cluster: int = 1000, device="cuda:0", query: bool = False) -> torch.Tensor:
+              per_cluster: int = 1000, device="cuda:0", query: bool = False,
+              distinct_leaves: bool = False) -> torch.Tensor:
     """Rows [start, start+count) of dataset H (or of the query set when query=True: same
-    mixture, independent noise, seed+1 -- out-of-sample queries)."""
+    mixture, independent noise, seed+1 -- out-of-sample queries).  distinct_leaves (queries only):
+    query i of the stream comes from leaf (i * 7919) mod n_leaf instead of a random one, so that any
+    n_leaf consecutive queries sit in n_leaf different leaf clusters -- a measurement aid: queries in
+    flight together then share no neighbourhood (bench.py --distinct-leaves)."""
     dev = torch.device(device)
     centres = _centres(n_total, d, per_cluster, seed, dev)
     out = torch.empty((count, d), device=dev, dtype=torch.float32)
@@ -75,7 +79,9 @@ def make_rows(n_total: int, d: int, start: int, count: int, seed: int = 42,
         g.manual_seed((seed + (1 if query else 0)) * 1000003 + c * 7919 + (5 if query else 0))
         noise = torch.randn((CHUNK, d), generator=g, device=dev, dtype=torch.float32)
         ids = torch.arange(lo, hi, device=dev)
-        if query:  # queries pick a leaf uniformly at random
+        if query and distinct_leaves:
+            leaf = (ids * 7919) % centres.shape[0]
+        elif query:  # queries pick a leaf uniformly at random
             leaf = torch.randint(0, centres.shape[0], (CHUNK,), generator=g, device=dev)
         else:
             leaf = _leaf_of(ids, n_total, per_cluster)
