@@ -568,6 +568,14 @@ isl_status isl_row_sumsq_bf16(const uint16_t* rows, uint64_t n, uint64_t d, floa
 isl_status isl_distance_matrix_bf16_norms(int32_t metric, const uint16_t* queries, uint64_t nq, const uint16_t* rows,
                                           uint64_t n, uint64_t d, const float* q_sumsq, const float* row_sumsq,
                                           float* out, int32_t mem, int32_t device, void* stream);
+/* The same GEMM, enqueued on `stream` and nothing else: device buffers only, q_sumsq / row_sumsq required
+ * (except for ISL_METRIC_DOT), no allocation, no synchronisation -- the caller's next work on `stream`
+ * finds the distances in `out`.  For callers that walk resident rows block by block (config 5: 153 blocks
+ * of 65536 rows per query batch) and must not let the chip idle between two blocks.  Same outputs, bit
+ * for bit.  Replaces Distance::batch_calculate (distance.rs:32-34) over a block of rows. */
+isl_status isl_distance_matrix_bf16_enqueue(int32_t metric, const uint16_t* queries, uint64_t nq, const uint16_t* rows,
+                                            uint64_t n, uint64_t d, const float* q_sumsq, const float* row_sumsq,
+                                            float* out, int32_t device, void* stream);
 /* isl_bruteforce_topk over bf16 rows and queries: blocks of isl_distance_matrix_bf16 + the same running
  * top-k (ties towards the smaller id), exact under the bf16 GEMM's distances.  Ground truth and exact
  * kNN lists at sizes where the float32 GEMM would take tens of minutes (10M x 10M x 768). */

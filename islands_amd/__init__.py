@@ -114,13 +114,31 @@ def distance_matrix(metric: DistanceMetric, queries, rows, device: int = 0) -> n
     return out
 
 
-def distance_matrix_bf16(metric: DistanceMetric, queries_bits, rows_bits, device: int = 0) -> np.ndarray:
-    """distance_matrix over bf16 bit patterns (u16) on the bf16 matrix cores -> [nq, n] f32."""
+def distance_matrix_bf16(metric: DistanceMetric, queries_bits, rows_bits, device: int = 0, q_sumsq=None,
+                         row_sumsq=None) -> np.ndarray:
+    """distance_matrix over bf16 bit patterns (u16) on the bf16 matrix cores -> [nq, n] f32.  q_sumsq /
+    row_sumsq: row_sumsq_bf16 of the operands when the caller keeps them (same outputs, bit for bit)."""
     q = np.ascontiguousarray(queries_bits, dtype=np.uint16)
     r = np.ascontiguousarray(rows_bits, dtype=np.uint16)
     out = np.zeros((q.shape[0], r.shape[0]), dtype=np.float32)
-    _check(_ffi.lib().isl_distance_matrix_bf16(int(metric), _ptr(q), q.shape[0], _ptr(r), r.shape[0],
-                                               q.shape[1], _ptr(out), MEM_HOST, device, None))
+    if q_sumsq is None and row_sumsq is None:
+        _check(_ffi.lib().isl_distance_matrix_bf16(int(metric), _ptr(q), q.shape[0], _ptr(r), r.shape[0],
+                                                   q.shape[1], _ptr(out), MEM_HOST, device, None))
+    else:
+        qs = None if q_sumsq is None else np.ascontiguousarray(q_sumsq, dtype=np.float32)
+        rs = None if row_sumsq is None else np.ascontiguousarray(row_sumsq, dtype=np.float32)
+        _check(_ffi.lib().isl_distance_matrix_bf16_norms(int(metric), _ptr(q), q.shape[0], _ptr(r), r.shape[0],
+                                                         q.shape[1], None if qs is None else _ptr(qs),
+                                                         None if rs is None else _ptr(rs), _ptr(out), MEM_HOST,
+                                                         device, None))
+    return out
+
+
+def row_sumsq_bf16(rows_bits, device: int = 0) -> np.ndarray:
+    """Sum of squares of every row of a bf16 matrix (u16 bit patterns) as the distance epilogues take it."""
+    r = np.ascontiguousarray(rows_bits, dtype=np.uint16)
+    out = np.zeros(r.shape[0], dtype=np.float32)
+    _check(_ffi.lib().isl_row_sumsq_bf16(_ptr(r), r.shape[0], r.shape[1], _ptr(out), MEM_HOST, device, None))
     return out
 
 

@@ -140,6 +140,8 @@ SIGNATURES = {
     "isl_row_sumsq_bf16": (i32, [C.c_void_p, u64, u64, C.c_void_p, i32, i32, C.c_void_p]),
     "isl_distance_matrix_bf16_norms": (i32, [i32, C.c_void_p, u64, C.c_void_p, u64, u64, C.c_void_p, C.c_void_p,
                                              C.c_void_p, i32, i32, C.c_void_p]),
+    "isl_distance_matrix_bf16_enqueue": (i32, [i32, C.c_void_p, u64, C.c_void_p, u64, u64, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, i32, C.c_void_p]),
     "isl_bruteforce_topk_bf16": (i32, [i32, C.c_void_p, u64, C.c_void_p, u64, u64, u64, C.c_void_p,
                                        C.c_void_p, C.c_void_p, i32, i32, C.c_void_p]),
     "isl_merge_topk": (i32, [u64, u64, u64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u64,

@@ -291,6 +291,27 @@ isl_status isl_distance_matrix_bf16_norms(int32_t metric, const uint16_t* querie
   return ISL_OK;
 }
 
+// The same GEMM, enqueued only: device buffers, the sums of squares handed in, nothing allocated and nothing
+// waited for -- the caller's next kernel on `stream` (a top-k over the block, the next block's call) finds the
+// distances there.  A call that synchronises leaves the chip idle between two blocks and lets it drop its
+// clocks (1.93 ms per 4096 x 65536 x 4096 block alone against 1.70 back to back: DESIGN.md section 3.4).
+isl_status isl_distance_matrix_bf16_enqueue(int32_t metric, const uint16_t* queries, uint64_t nq, const uint16_t* rows,
+                                            uint64_t n, uint64_t d, const float* q_sumsq, const float* row_sumsq,
+                                            float* out, int32_t device, void* stream) {
+  if (nq == 0 || n == 0) return ISL_OK;
+  if (!queries || !rows || !out) return isl::fail(ISL_ERR_INVALID_ARGUMENT, "NULL buffer");
+  if (metric != ISL_METRIC_DOT && (!q_sumsq || !row_sumsq))
+    return isl::fail(ISL_ERR_INVALID_ARGUMENT, "the enqueue-only form takes the sums of squares from the caller (isl_row_sumsq_bf16)");
+  if (d == 0) return isl::fail(ISL_ERR_EMPTY_COLLECTION, "Empty vector collection");
+  if (d % 64) return isl::fail(ISL_ERR_UNSUPPORTED, "bf16 distance matrix: the dimension must be a multiple of 64");
+  if (nq > 0xFFFFFFFFull || n > 0xFFFFFFFFull || ((nq + 127) / 128) * ((n + 127) / 128) >= 0x7FFFFFFFull)
+    return isl::fail(ISL_ERR_UNSUPPORTED, "matrix too large for one launch: split the rows");
+  if (((uintptr_t)queries & 15) || ((uintptr_t)rows & 15))
+    return isl::fail(ISL_ERR_INVALID_ARGUMENT, "bf16 matrices must be 16-byte aligned");
+  ISL_TRY(isl::use_device(device));
+  return launch_distance_gemm_bf16(metric, queries, rows, q_sumsq, row_sumsq, out, nq, n, d, n, (hipStream_t)stream);
+}
+
 isl_status isl_distance_matrix(int32_t metric, const float* queries, uint64_t nq, const float* rows,
                                uint64_t n, uint64_t d, float* out, int32_t mem, int32_t device,
                                void* stream) {

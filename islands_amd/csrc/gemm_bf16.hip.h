@@ -584,46 +584,84 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_ph8(const __bf16* __restrict
     constexpr uint32_t EP_PITCH = 72;
     float* const ep = reinterpret_cast<float*>(lds) + wave * (8 * EP_PITCH);
     const uint32_t g4 = lane >> 4, c = lane & 15;
+    // VAR & 8 (round 4): the wave's 128 row norms come through LDS, loaded ONCE in front of the stores.  On gfx950
+    // loads and stores share vmcnt and the compiler must take a counter with both kinds pending as unordered:
+    // every R[m] read between the stores became `global_load_dword; s_waitcnt vmcnt(0)` -- 32 times per lane
+    // the wave sat until ALL its earlier result stores were acknowledged (the cosine kernel's 0.19 ms over the
+    // dot kernel's 1.75 at 4096 x 65536 x 4096).  And when no (row, column) pair of the wave's block has
+    // |a|^2 |w|^2 below FLT_MIN (min over rows x min over columns: float multiplication is monotonic), the
+    // block takes epi_cosine's main branch without the per-element test: same bits.
+    constexpr bool LNORM = (VAR & 8) != 0 && ROWNORM;
+    float* const rnl = reinterpret_cast<float*>(lds) + 8 * (8 * EP_PITCH) + wave * 128;
+    int fast_i = 0;
+    if constexpr (LNORM) {
+      float mr = 3.0e38f, mc = 3.0e38f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int t = 0; t < 2; ++t) {
+        const uint64_t m = m0 + wm + lane + 64 * t;
+        const float v = m < M ? R[m] : 0.0f;
+        rnl[lane + 64 * t] = v;
+        if (m < M) mr = fminf(mr, v);
+      }
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {  // rows 4 g4 + 2 h + {0, 1} of the 16-row block -> patch rows 2 g4 + {0, 1}
+      for (int j = 0; j < 4; ++j)
+        if (n0 + wn + j * 16 + c < N) mc = fminf(mc, bvs[j]);
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          const int r = 2 * h + rr;
-          const uint64_t m = m0 + wm + i * 16 + 4 * g4 + r;
-          const float rm = (ROWNORM && m < M) ? R[m] : 0.0f;
+      for (int off = 32; off; off >>= 1) {
+        mr = fminf(mr, __shfl_xor(mr, off));
+        mc = fminf(mc, __shfl_xor(mc, off));
+      }
+      fast_i = __builtin_amdgcn_readfirstlane((ACT == EPI_COSINE && mr * mc >= 1.17549435e-38f) ? 1 : 0);
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+    }
+    auto body = [&](auto fast_) {
+      constexpr bool FAST = decltype(fast_)::value;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float v = acc4[i][j][r];
-            if (ACT == EPI_COSINE) v = epi_cosine(v, rm, bvs[j]);
-            else if (ACT == EPI_DOT) v = -v;
-            else v = epi_euclidean(v, rm, bvs[j]);
-            ep[(g4 * 2 + rr) * EP_PITCH + j * 16 + c] = v;
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const uint32_t lrow = 4 * t + g4;  // patch row: group lrow / 2, row rr = lrow % 2
-          const uint64_t m = m0 + wm + i * 16 + 4 * (lrow >> 1) + 2 * h + (lrow & 1u);
-          const uint64_t n = n0 + wn + c * 4;
-          const floatx4_t v = *reinterpret_cast<const floatx4_t*>(&ep[lrow * EP_PITCH + c * 4]);
-          if (m < M) {
-            float* out = C + m * ldc + n;
-            if (n + 3 < N) {
-              *reinterpret_cast<floatx4_t*>(out) = v;
-            } else {
+        for (int h = 0; h < 2; ++h) {  // rows 4 g4 + 2 h + {0, 1} of the 16-row block -> patch rows 2 g4 + {0, 1}
 #pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (n + e < N) out[e] = v[e];
+          for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * h + rr;
+            const uint64_t m = m0 + wm + i * 16 + 4 * g4 + r;
+            float rm;
+            if constexpr (LNORM) rm = rnl[i * 16 + 4 * g4 + r];
+            else rm = (ROWNORM && m < M) ? R[m] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float v = acc4[i][j][r];
+              if (ACT == EPI_COSINE) v = FAST ? 1.0f - v * __builtin_amdgcn_rsqf(rm * bvs[j]) : epi_cosine(v, rm, bvs[j]);
+              else if (ACT == EPI_DOT) v = -v;
+              else v = epi_euclidean(v, rm, bvs[j]);
+              ep[(g4 * 2 + rr) * EP_PITCH + j * 16 + c] = v;
             }
           }
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const uint32_t lrow = 4 * t + g4;  // patch row: group lrow / 2, row rr = lrow % 2
+            const uint64_t m = m0 + wm + i * 16 + 4 * (lrow >> 1) + 2 * h + (lrow & 1u);
+            const uint64_t n = n0 + wn + c * 4;
+            const floatx4_t v = *reinterpret_cast<const floatx4_t*>(&ep[lrow * EP_PITCH + c * 4]);
+            if (m < M) {
+              float* out = C + m * ldc + n;
+              if (n + 3 < N) {
+                *reinterpret_cast<floatx4_t*>(out) = v;
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (n + e < N) out[e] = v[e];
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("" ::: "memory");
         }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
-      }
+    };
+    if (LNORM && fast_i) body(std::true_type{});
+    else body(std::false_type{});
     return;
   }
 #pragma unroll
@@ -966,7 +1004,7 @@ void launch_gemm_bf16_dma(const __bf16* A, const __bf16* W, const float* bias, c
     // distance epilogues: rows stored whole through the LDS patch (gemm_tn_bf16_ph8, VAR & 4); ISL_GEMM_EPT=0: A/B
     static const bool ept = [] { const char* e = getenv("ISL_GEMM_EPT"); return !e || atoi(e) != 0; }();
     if (use_big && ph8 && ept && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0) {
-      auto kern = gemm_tn_bf16_ph8<ACT, RES, C16, 4>;
+      auto kern = gemm_tn_bf16_ph8<ACT, RES, C16, 12>;
       constexpr size_t lds = 2 * (256 + 256) * HBK * 2;
       static const bool once = [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -240,22 +240,28 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_f32_dma(const float* __r
       a[i] = *reinterpret_cast<const float4*>(ab + ra * 128u + ((cl ^ ((ra >> 1) & 7u)) << 4));
     }
   };
-  auto finish = [&](float v, uint64_t m, uint64_t n, float bv) -> float {  // the epilogue of one element
+  // the epilogue of one element; rv = the residual element R[m][n] (RES) or the row's squared norm R[m]
+  // (distance epilogues), loaded by the caller: a load between the result stores costs a full
+  // `s_waitcnt vmcnt(0)` on gfx950 (loads and stores share the counter, and with both kinds pending the
+  // compiler must treat it as unordered), i.e. the wave sits until its earlier stores are acknowledged
+  auto finish = [&](float v, float bv, float rv) -> float {
     if (ACT <= 2) {
       v += bv;
       if (ACT == 1) v = gelu_erf_f(v);
       if (ACT == 2) v = gelu_tanh_f(v);
-      if (RES) v += R[m * N + n];
+      if (RES) v += rv;
     } else if (ACT == EPI_COSINE) {
-      v = epi_cosine(v, R[m], bv);
+      v = epi_cosine(v, rv, bv);
     } else if (ACT == EPI_DOT) {
       v = -v;
     } else if (ACT == EPI_EUCLIDEAN) {
-      v = epi_euclidean(v, R[m], bv);
+      v = epi_euclidean(v, rv, bv);
     }
     return v;
   };
-  const bool vec_ok = (N & 3u) == 0 && (ldc & 3u) == 0 && ((uintptr_t)C & 15u) == 0 && (!bias || ((uintptr_t)bias & 15u) == 0);
+  constexpr bool ROWNORM = ACT == EPI_COSINE || ACT == EPI_EUCLIDEAN;
+  const bool vec_ok = (N & 3u) == 0 && (ldc & 3u) == 0 && ((uintptr_t)C & 15u) == 0 && (!bias || ((uintptr_t)bias & 15u) == 0) &&
+                      (!RES || ((uintptr_t)R & 15u) == 0);
 
   uint32_t t = blockIdx.x, par = 0;
   uint64_t m0, n0;
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_f32_dma(const float* __r
           for (int r = 0; r < 16; ++r) {
             const uint64_t m = m0 + wm + i * 32 + 8 * (r / 4) + 4 * kh + (r % 4);
             if (m >= M) continue;
-            C[m * ldc + n] = finish(acc[i][j][r], m, n, bv);
+            C[m * ldc + n] = finish(acc[i][j][r], bv, RES ? R[m * N + n] : ROWNORM ? R[m] : 0.0f);
           }
         }
     } else {
@@ -337,6 +343,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_f32_dma(const float* __r
       __syncthreads();  // everyone is done reading the last slab
       float* sc = reinterpret_cast<float*>(lds + ((par + nk - 1) & 1u) * BUF + wave * SCRATCH);
       constexpr uint32_t WCOLS = 32 * NF;  // the wave's columns
+      constexpr uint32_t NQ = 32 * WCOLS / 256, RPQ = 64 / (WCOLS / 4);  // store rounds per row block; rows per round
+      // a lane's columns are the same in every round (c4 = lane mod WCOLS / 4): its bias values are loaded once
+      // per tile, and a row block's residual elements / row norms in one go before the block's stores
+      const uint32_t c4 = lane % (WCOLS / 4), row0 = lane / (WCOLS / 4);
+      const uint64_t nv = n0 + wn + 4 * c4;
+      // (loads are unconditional on clamped addresses and pinned by an empty asm: the compiler otherwise sinks
+      // each load back to its use between the stores)
+      const uint64_t nvc = nv < N ? nv : 0;
+      float4 bv4 = float4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (vec_ok && bias) {
+        bv4 = *reinterpret_cast<const float4*>(bias + nvc);
+        asm volatile("" : "+v"(bv4.x), "+v"(bv4.y), "+v"(bv4.z), "+v"(bv4.w));
+      }
 #pragma unroll
       for (int i = 0; i < MF; ++i) {
 #pragma unroll
@@ -344,25 +363,47 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_f32_dma(const float* __r
 #pragma unroll
           for (int r = 0; r < 16; ++r) sc[(8 * (r / 4) + 4 * kh + (r % 4)) * WCOLS + 32 * j + c32] = acc[i][j][r];
         // (LDS operations of one wave complete in order: the reads below see the writes above)
+        if (vec_ok) {
+          float4 rv4[NQ];
+          float rn[NQ];
 #pragma unroll
-        for (uint32_t q = 0; q < 32 * WCOLS / 256; ++q) {
-          const uint32_t e4 = q * 64 + lane, row = e4 / (WCOLS / 4), c4 = e4 % (WCOLS / 4);
-          const float4 v = *reinterpret_cast<const float4*>(sc + row * WCOLS + 4 * c4);
-          const uint64_t m = m0 + wm + 32 * i + row, n = n0 + wn + 4 * c4;
-          if (m >= M || n >= N) continue;
-          if (vec_ok) {
-            const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n) : float4{0.0f, 0.0f, 0.0f, 0.0f};
+          for (uint32_t q = 0; q < NQ; ++q) {
+            const uint64_t m = m0 + wm + 32 * i + q * RPQ + row0, mc = m < M ? m : (uint64_t)M - 1;
+            rv4[q] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            rn[q] = 0.0f;
+            if (RES) rv4[q] = *reinterpret_cast<const float4*>(R + mc * N + nvc);
+            if (ROWNORM) rn[q] = R[mc];
+          }
+#pragma unroll
+          for (uint32_t q = 0; q < NQ; ++q) {
+            if (RES) asm volatile("" : "+v"(rv4[q].x), "+v"(rv4[q].y), "+v"(rv4[q].z), "+v"(rv4[q].w));
+            if (ROWNORM) asm volatile("" : "+v"(rn[q]));
+          }
+#pragma unroll
+          for (uint32_t q = 0; q < NQ; ++q) {
+            const uint32_t row = q * RPQ + row0;
+            const float4 v = *reinterpret_cast<const float4*>(sc + row * WCOLS + 4 * c4);
+            const uint64_t m = m0 + wm + 32 * i + row;
+            if (m >= M || nv >= N) continue;
             float4 o;
-            o.x = finish(v.x, m, n, bv.x);
-            o.y = finish(v.y, m, n + 1, bv.y);
-            o.z = finish(v.z, m, n + 2, bv.z);
-            o.w = finish(v.w, m, n + 3, bv.w);
-            *reinterpret_cast<float4*>(C + m * ldc + n) = o;
-          } else {
+            o.x = finish(v.x, bv4.x, RES ? rv4[q].x : rn[q]);
+            o.y = finish(v.y, bv4.y, RES ? rv4[q].y : rn[q]);
+            o.z = finish(v.z, bv4.z, RES ? rv4[q].z : rn[q]);
+            o.w = finish(v.w, bv4.w, RES ? rv4[q].w : rn[q]);
+            *reinterpret_cast<float4*>(C + m * ldc + nv) = o;
+          }
+        } else {
+#pragma unroll
+          for (uint32_t q = 0; q < NQ; ++q) {
+            const uint32_t row = q * RPQ + row0;
+            const float4 v = *reinterpret_cast<const float4*>(sc + row * WCOLS + 4 * c4);
+            const uint64_t m = m0 + wm + 32 * i + row;
+            if (m >= M || nv >= N) continue;
             const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-              if (n + u < N) C[m * ldc + n + u] = finish(vv[u], m, n + u, bias ? bias[n + u] : 0.0f);
+              if (nv + u < N)
+                C[m * ldc + nv + u] = finish(vv[u], bias ? bias[nv + u] : 0.0f, RES ? R[m * N + nv + u] : ROWNORM ? R[m] : 0.0f);
           }
         }
       }

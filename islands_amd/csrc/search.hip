@@ -561,6 +561,10 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
   p.q_evals = nullptr;
   static const uint32_t seq_max_env = [] { const char* e = getenv("ISL_SEQ_MAX"); return e ? (uint32_t)atoi(e) : 0u; }();
   p.seq_max = seq_max_env;
+  {  // ISL_AGE_PRIO=h: waves raise their priority every h expansions of their query (read per call: A/B in one process)
+    const char* e = getenv("ISL_AGE_PRIO");
+    p.age_prio = e ? (uint32_t)std::max(0, atoi(e)) : 0u;
+  }
   if (tl) {
     const isl_pq* pq = idx->pq;
     const uint64_t want = std::max<uint64_t>(nq, 1) * pq->m * pq->K;
@@ -864,7 +868,8 @@ __global__ __launch_bounds__(64) void assign_slots_kernel(const uint32_t* __rest
   // whose narrowest GEMM still fits ONE wave of tiles), plus the rest when that rest nearly fills a wave
   // anyway; what is left over is un-claimed below and reported again next round, when it is batched with
   // that round's misses.  quantum == 0: everything (a provider whose shapes were not analysed).
-  uint32_t n = *n_ptr;
+  const uint32_t n_all = *n_ptr;
+  uint32_t n = n_all;
   if (quantum && n >= quantum) {
     const uint32_t whole = chunk ? (n / chunk) * chunk : 0u, rem = n - whole;
     const uint32_t r = rem % quantum;
@@ -905,7 +910,7 @@ __global__ __launch_bounds__(64) void assign_slots_kernel(const uint32_t* __rest
     walked += step;
   }
   if (done > n) done = n;
-  for (uint32_t i = done + lane; i < n; i += 64) slot_of[uniq[i]] = kNoSlot;
+  for (uint32_t i = done + lane; i < n_all; i += 64) slot_of[uniq[i]] = kNoSlot;  // (the quantum's left-overs too)
   if (lane == 0) { head_word[0] = pos; head_word[1] = fill; *taken = done; }
 }
 

@@ -625,6 +625,58 @@ def test_distance_matrix_bf16_matches_batch_calculate(orc, metric, nq, n, d):
     assert e.value.kind == "Unsupported"
 
 
+@pytest.mark.parametrize("metric", [ia.DistanceMetric.Cosine, ia.DistanceMetric.Euclidean, ia.DistanceMetric.DotProduct])
+def test_distance_matrix_bf16_large_tile_forms_agree(orc, metric):
+    """Shapes that take the 256 x 256 eight-phase kernel (>= 512 tiles, ragged edges): the call that computes the
+    sums of squares itself, the one that is handed them (isl_row_sumsq_bf16) and the enqueue-only form over device
+    buffers give the same bits; sampled rows agree with the reference's sequential sums to 1e-5.  Rows with
+    zero / denormal-product norms sit in some tiles only: those blocks take the careful cosine branch, the
+    others the branch-free one (gemm_tn_bf16_ph8, VAR 12)."""
+    import ctypes as C
+    import torch
+    from islands_amd import _ffi
+    nq, n, d = 300, 110_000, 128
+    def to_bf16(x):
+        b = (x.view(np.uint32) >> 16).astype(np.uint16)
+        return b, (b.astype(np.uint32) << 16).view(np.float32)
+    rows = clustered_vectors(n, d, 3)
+    q = clustered_vectors(nq, d, 4)
+    rows[5] = 0.0
+    rows[70_001] *= np.float32(1e-20)
+    rows[70_002] *= np.float32(3e-12)
+    q[2] *= np.float32(1e-19)
+    q[290] = 0.0
+    rb, rw = to_bf16(rows)
+    qb, qw = to_bf16(q)
+    a = ia.distance_matrix_bf16(metric, qb, rb)
+    qs, rs = ia.row_sumsq_bf16(qb), ia.row_sumsq_bf16(rb)
+    b = ia.distance_matrix_bf16(metric, qb, rb, q_sumsq=qs, row_sumsq=rs)
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    dev = torch.device("cuda:0")
+    tq, tr = torch.from_numpy(qb.view(np.int16)).to(dev), torch.from_numpy(rb.view(np.int16)).to(dev)
+    tqs, trs = torch.from_numpy(qs).to(dev), torch.from_numpy(rs).to(dev)
+    out = torch.full((nq, n), float("nan"), device=dev)
+    torch.cuda.synchronize()
+    ia._check(_ffi.lib().isl_distance_matrix_bf16_enqueue(
+        int(metric), C.c_void_p(tq.data_ptr()), nq, C.c_void_p(tr.data_ptr()), n, d, C.c_void_p(tqs.data_ptr()),
+        C.c_void_p(trs.data_ptr()), C.c_void_p(out.data_ptr()), 0, None))
+    torch.cuda.synchronize()
+    c = out.cpu().numpy()
+    assert (a.view(np.uint32) == c.view(np.uint32)).all()
+    for i in (0, 2, 131, 290, 299):
+        want = orc.batch_distance(int(metric), qw[i], rw)
+        if metric == ia.DistanceMetric.Euclidean:
+            assert np.abs(a[i] ** 2 - want ** 2).max() < 1e-5
+        else:
+            assert np.abs(a[i] - want).max() < 1e-5
+    if metric != ia.DistanceMetric.DotProduct:
+        with pytest.raises(ia.CoreError) as e:
+            ia._check(_ffi.lib().isl_distance_matrix_bf16_enqueue(
+                int(metric), C.c_void_p(tq.data_ptr()), nq, C.c_void_p(tr.data_ptr()), n, d, None, None,
+                C.c_void_p(out.data_ptr()), 0, None))
+        assert e.value.kind == "InvalidArgument"
+
+
 def test_distance_matrix_cosine_with_tiny_norms(orc):
     """Rows whose squared norms multiply to a denormal (or to zero): the 1-ulp rsq of the GEMM epilogue
     flushes such an input to zero -- those elements must take the reference's own form,

@@ -126,6 +126,10 @@ int main(int argc, char** argv) {
         (void)run<EPI_COSINE, true, 4>(a, w, c1, m, n, k, 1);
         const hipError_t e3 = hipDeviceSynchronize();
         printf("   8-phase kernel, LDS-transposed epilogue: %llu differing elements (%s)\n", differing(c0, c1, (uint64_t)m * n), hipGetErrorString(e3));
+        (void)hipMemset(c1, 0xFF, (size_t)m * n * 4);
+        (void)run<EPI_COSINE, true, 12>(a, w, c1, m, n, k, 1);
+        const hipError_t e4 = hipDeviceSynchronize();
+        printf("   8-phase kernel, VAR 12: %llu differing elements (%s)\n", differing(c0, c1, (uint64_t)m * n), hipGetErrorString(e4));
       }
       if (k >= 128 && n % 4 == 0) {
         (void)hipMemset(c1, 0xFF, (size_t)m * n * 4);
@@ -165,6 +169,9 @@ int main(int argc, char** argv) {
     const float p3 = run_p<EPI_COSINE>(A, W, C1, M, N, K, reps), p4 = run_p<EPI_COSINE, 1>(A, W, C1, M, N, K, reps), p5 = run_p<EPI_COSINE, 2>(A, W, C1, M, N, K, reps);
     const float e0 = run<EPI_DOT, true, 4>(A, W, C1, M, N, K, reps), e1 = run<EPI_COSINE, true, 4>(A, W, C1, M, N, K, reps);
     printf("   8-phase with the LDS-transposed epilogue: dot %.3f ms %.1f TF | cosine %.3f ms %.1f TF\n", e0, fl / e0 / 1e9, e1, fl / e1 / 1e9);
+    const float e2 = run<EPI_COSINE, true, 12>(A, W, C1, M, N, K, reps), e3 = run<EPI_EUCLIDEAN, true, 12>(A, W, C1, M, N, K, reps), e4 = run<EPI_EUCLIDEAN, true, 4>(A, W, C1, M, N, K, reps);
+    printf("   ... + row norms through LDS, no load between the stores (VAR 12): cosine %.3f ms %.1f TF | euclidean %.3f ms %.1f TF (VAR 4: %.1f TF)\n",
+           e2, fl / e2 / 1e9, e3, fl / e3 / 1e9, fl / e4 / 1e9);
     printf("   persistent: dot %.3f ms %.1f TF (non-temporal stores %.1f, per-element epilogue %.1f) | cosine %.3f ms %.1f TF (non-temporal stores %.1f, per-element epilogue %.1f)\n",
            p0, fl / p0 / 1e9, fl / p1 / 1e9, fl / p2 / 1e9, p3, fl / p3 / 1e9, fl / p4 / 1e9, fl / p5 / 1e9);
     fflush(stdout);
@@ -175,6 +182,24 @@ int main(int argc, char** argv) {
   (void)hipMemset(C1, 0xFF, (size_t)M * N * 4);
   (void)run<EPI_COSINE, true, 4>(A, W, C1, M, N, K, 1);
   printf("cosine outputs of the 8-phase kernel with the LDS-transposed epilogue, differing elements: %llu\n", differing(C0, C1, (uint64_t)M * N));
+  (void)hipMemset(C1, 0xFF, (size_t)M * N * 4);
+  (void)run<EPI_COSINE, true, 12>(A, W, C1, M, N, K, 1);
+  printf("cosine outputs of the 8-phase kernel, VAR 12 (row norms through LDS, branch-free block), differing elements: %llu\n", differing(C0, C1, (uint64_t)M * N));
+  {  // tiny norms in one corner: that block must take the careful branch, every bit as before
+    std::vector<float> hq(M, 1.0f), hr(N, 1.0f);
+    for (uint32_t i = 0; i < 40 && i < M; ++i) hq[i] = (i % 3 == 0) ? 0.0f : 1e-30f;
+    for (uint32_t i = 100; i < 180 && i < N; ++i) hr[i] = (i % 5 == 0) ? 0.0f : 3e-12f;
+    (void)hipMemcpy(qn, hq.data(), (size_t)M * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(rn, hr.data(), (size_t)N * 4, hipMemcpyHostToDevice);
+    (void)run<EPI_COSINE, false>(A, W, C0, M, N, K, 1);
+    (void)hipMemset(C1, 0xFF, (size_t)M * N * 4);
+    (void)run<EPI_COSINE, true, 12>(A, W, C1, M, N, K, 1);
+    printf("   the same with zero / tiny norms in rows 0..39 and columns 100..179: %llu\n", differing(C0, C1, (uint64_t)M * N));
+    std::vector<float> ones(N > M ? N : M, 1.0f);
+    (void)hipMemcpy(rn, ones.data(), (size_t)N * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(qn, ones.data(), (size_t)M * 4, hipMemcpyHostToDevice);
+    (void)run<EPI_COSINE, false>(A, W, C0, M, N, K, 1);
+  }
   (void)hipMemset(C1, 0xFF, (size_t)M * N * 4);
   (void)run_p<EPI_COSINE>(A, W, C1, M, N, K, 1);
   printf("cosine outputs of the persistent kernel, differing elements: %llu\n", differing(C0, C1, (uint64_t)M * N));

@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--batches", type=int, default=20)
     ap.add_argument("--nq", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--age-prio", default="", help="comma list of ISL_AGE_PRIO settings (0 = off) to run every leg under, "
+                    "interleaved in one process: waves raise their issue priority every h expansions of their query")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     N, d, nq, k, ef, B = a.nodes, a.dim, a.nq, 10, 128, a.batches
@@ -90,15 +92,20 @@ def main():
     gc.disable()
     res = {"workload": f"{N} x {d} f32 rows, {B} batches of {nq} distinct queries, k={k}, ef={ef}", "legs": {}}
     ref = None
+    ages = [int(v) for v in a.age_prio.split(",") if v != ""] or [None]
     for r in range(a.reps):
         for name, (plan, depth) in plans.items():
-            out = leg(plan, depth)
-            ids = oi.clone()
-            if ref is None:
-                ref = ids
-            out["ids_equal_first_leg"] = bool((ids == ref).all().item())
-            res["legs"].setdefault(name, []).append(out)
-            print(f"[probe] rep {r} {name}: end {out['end_ms']} ms, {out['queries_per_s']} q/s", file=sys.stderr, flush=True)
+            for age in ages:
+                if age is not None:
+                    os.environ["ISL_AGE_PRIO"] = str(age)
+                out = leg(plan, depth)
+                ids = oi.clone()
+                if ref is None:
+                    ref = ids
+                out["ids_equal_first_leg"] = bool((ids == ref).all().item())
+                key = name if age is None else f"{name}@age_prio={age}"
+                res["legs"].setdefault(key, []).append(out)
+                print(f"[probe] rep {r} {key}: end {out['end_ms']} ms, {out['queries_per_s']} q/s", file=sys.stderr, flush=True)
     print(json.dumps(res))
 
 
