@@ -173,7 +173,7 @@ def measure_traffic(args):
     child = [sys.executable, os.path.abspath(__file__), "--traffic-child", "--gpus", "1", "--steps", "4",
              "--warmup", "1", "--pipeline", "1", "--nodes", str(args.nodes), "--dim", str(args.dim), "--nq",
              str(args.nq), "--k", str(args.k), "--ef", str(args.ef), "--per-cluster", str(args.per_cluster),
-             "--row-dtype", args.row_dtype, "--dataset", args.dataset, "--distinct-batches",
+             "--row-dtype", args.row_dtype, "--dataset", args.dataset, "--latent", str(args.latent), "--distinct-batches",
              str(args.distinct_batches), "--graph", args.graph, "--no-cpu-baseline", "--no-host-path", "--no-traffic"] + \
         (["--distinct-leaves"] if args.distinct_leaves else [])
     cmd = [rp, "--pmc", "FETCH_SIZE", "--kernel-include-regex", "leann_search_fast", "-d", out, "-o", "p",
@@ -272,10 +272,13 @@ def main():
     ap.add_argument("--row-dtype", choices=["f32", "bf16"], default="f32",
                     help="storage type of the embedding rows (bf16: rows rounded to bf16, stored as "
                          "such, arithmetic still f32 on the widened values; not the headline config)")
-    ap.add_argument("--dataset", choices=["G", "U"], default="G",
+    ap.add_argument("--dataset", choices=["G", "U", "M"], default="G",
                     help="G: the headline clustered mixture; U: i.i.d. uniform [-1,1) rows as in "
                          "benches/hnsw_benchmarks.rs:9-14 (SURVEY 8d asks for both; no cluster structure, "
-                         "so recall at ef=128 is whatever the data allows)")
+                         "so recall at ef=128 is whatever the data allows); M: rows on a smooth --latent-dimensional "
+                         "manifold (tools/synth.py::make_manifold: no clusters, no tree -- a dataset no graph builder "
+                         "of this repository was designed around; use it with --graph knn)")
+    ap.add_argument("--latent", type=int, default=16, help="dataset M: intrinsic dimension")
     ap.add_argument("--graph", choices=["harness", "knn", "product"], default="harness",
                     help="who builds the graph the search walks.  harness (headline): tools/synth.py::build_graph "
                          "(k-means medoid levels flattened into one layer, diversified links); knn: every node's 30 "
@@ -375,6 +378,8 @@ def main():
         t0 = time.time()
         if args.dataset == "U":
             x = synth.make_uniform(n_local, d, 42, device=dev, start=lo)  # this rank's rows only
+        elif args.dataset == "M":
+            x = synth.make_manifold(n_local, d, 42, device=dev, start=lo, latent=args.latent)
         else:
             x = synth.make_rows(N, d, lo, n_local, per_cluster=args.per_cluster, device=dev)
         x16 = None
@@ -440,6 +445,8 @@ def main():
             qoff = (b + (rank * nb_batches if (world > 1 and not shard_mode) else 0)) * nq
             if args.dataset == "U":
                 q = synth.make_uniform(nq, d, 43 + qoff, device=dev)
+            elif args.dataset == "M":  # out-of-sample points of the same density (their own seed stream)
+                q = synth.make_manifold(nq, d, 4300 + qoff // max(nq, 1), device=dev, latent=args.latent)
             else:
                 q = synth.make_rows(N, d, qoff, nq, per_cluster=args.per_cluster, device=dev, query=True,
                                     distinct_leaves=args.distinct_leaves)
@@ -614,6 +621,8 @@ def main():
             "config": {
                 "workload": f"{n_local if args.rehearse_shard else N} x {d} {args.row_dtype} rows resident in HBM (in-memory provider), "
                             + ("hierarchical Gaussian mixture" if args.dataset == "G" else
+                               f"dataset M: rows on a smooth {args.latent}-dimensional linear manifold + isotropic noise, "
+                               "L2-normalised (tools/synth.py::make_manifold)" if args.dataset == "M" else
                                "dataset U: i.i.d. uniform [-1,1) rows (benches/hnsw_benchmarks.rs:9-14)") +
                             f", graph by {GRAPH_BUILDERS[args.graph]}, deg<= 60 (mean {gst['deg_mean']:.1f}), "
                             f"query batch {nq}, k={k}, ef={ef}, cosine",

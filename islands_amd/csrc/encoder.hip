@@ -355,6 +355,62 @@ __global__ __launch_bounds__(64) void pool_kernel(const float* __restrict__ hid,
   }
 }
 
+// the buffers one model pass works in: the encoder's own, or its side set
+struct EncWs {
+  float *x, *x1, *t, *qkv, *ctx, *inter;
+  void *x16, *x1_16;
+  float* d_mask;
+  int64_t *d_ids, *d_tt;
+  uint32_t* d_flag;
+};
+EncWs main_ws(const isl_encoder* e) {
+  return EncWs{e->x, e->x1, e->t, e->qkv, e->ctx, e->inter, e->x16, e->x1_16, e->d_mask, e->d_ids, e->d_tt, e->d_flag};
+}
+EncWs side_ws(const isl_encoder* e) {
+  const auto& s = e->side;
+  return EncWs{s.x, s.x1, s.t, s.qkv, s.ctx, s.inter, s.x16, s.x1_16, s.d_mask, s.d_ids, s.d_tt, s.d_flag};
+}
+
+void free_side(isl_encoder* e) {
+  auto& s = e->side;
+  void* olds[] = {s.x, s.x1, s.t, s.qkv, s.ctx, s.inter, s.d_mask, s.d_ids, s.d_tt, s.x16, s.x1_16};
+  for (void* p : olds)
+    if (p) (void)hipFree(p);
+  s.x = s.x1 = s.t = s.qkv = s.ctx = s.inter = s.d_mask = nullptr;
+  s.x16 = s.x1_16 = nullptr;
+  s.d_ids = s.d_tt = nullptr;
+  s.ws_tokens = 0;
+}
+
+// the side workspace for B sequences of padded length L, its stream and its two events
+isl_status ensure_side(isl_encoder* e, uint64_t B, uint64_t L) {
+  auto& s = e->side;
+  if (!s.stream) {
+    hipStream_t st = nullptr;
+    ISL_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    s.stream = st;
+  }
+  if (!s.ev_in) { hipEvent_t ev = nullptr; ISL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); s.ev_in = ev; }
+  if (!s.ev_out) { hipEvent_t ev = nullptr; ISL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); s.ev_out = ev; }
+  if (!s.d_flag && hipMalloc(&s.d_flag, 4) != hipSuccess) return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed");
+  const uint64_t tokens = B * L;
+  if (tokens <= s.ws_tokens) return ISL_OK;
+  free_side(e);
+  const uint64_t h = e->cfg.hidden, I = e->cfg.intermediate;
+  if (hipMalloc(&s.x, tokens * h * 4) != hipSuccess || hipMalloc(&s.x1, tokens * h * 4) != hipSuccess ||
+      hipMalloc(&s.t, tokens * h * 4) != hipSuccess || hipMalloc(&s.qkv, tokens * 3 * h * 4) != hipSuccess ||
+      hipMalloc(&s.ctx, tokens * h * 4) != hipSuccess || hipMalloc(&s.inter, tokens * I * 4) != hipSuccess ||
+      hipMalloc(&s.d_mask, tokens * 4) != hipSuccess || hipMalloc(&s.d_ids, tokens * 8) != hipSuccess ||
+      hipMalloc(&s.d_tt, tokens * 8) != hipSuccess || hipMalloc(&s.x16, tokens * h * 2) != hipSuccess ||
+      hipMalloc(&s.x1_16, tokens * h * 2) != hipSuccess) {
+    free_side(e);
+    return isl::fail(ISL_ERR_DEVICE, "hipMalloc failed for the encoder's side workspace (%llu tokens)",
+                     (unsigned long long)tokens);
+  }
+  s.ws_tokens = tokens;
+  return ISL_OK;
+}
+
 isl_status ensure_ws(isl_encoder* e, uint64_t B, uint64_t L) {
   const uint64_t tokens = B * L;
   if (tokens <= e->ws_tokens) return ISL_OK;
@@ -384,26 +440,27 @@ __global__ void fill_f32(float* p, uint64_t n, float v) {
 }
 
 // The model on B sequences of padded length L whose ids / types / mask already sit in the
-// workspace (e->d_ids, e->d_tt when has_tt, e->d_mask); the last hidden state is left in e->x.
-isl_status compute_forward(isl_encoder* e, bool has_tt, uint64_t B, uint64_t L, hipStream_t st) {
-  const isl_bert_config& c = e->cfg;
+// workspace (w.d_ids, w.d_tt when has_tt, w.d_mask); the last hidden state is left in w.x.
+isl_status compute_forward(isl_encoder* enc, const EncWs& w, bool has_tt, uint64_t B, uint64_t L, hipStream_t st) {
+  const EncWs* e = &w;  // (the body below reads its buffers through `e`)
+  const isl_bert_config& c = enc->cfg;
   const uint64_t M = B * L, h = c.hidden, I = c.intermediate;
   ISL_HIP(hipMemsetAsync(e->d_flag, 0, 4, st));
   const uint32_t dh = c.hidden / c.heads;
   static const bool valu_attention = getenv("ISL_ATTENTION_VALU") != nullptr;
   // bf16 mode: every GEMM input is kept as a bf16 copy written by its producer (LayerNorm,
   // attention, the GELU epilogue); ctx and inter only exist in bf16 then (in their f32 buffers)
-  const bool half = e->precision == ISL_DTYPE_BF16 && !e->layers16.empty() && h % 8 == 0 && I % 8 == 0 &&
+  const bool half = enc->precision == ISL_DTYPE_BF16 && !enc->layers16.empty() && h % 8 == 0 && I % 8 == 0 &&
                     (dh == 64 || dh == 32) && !valu_attention;
   __bf16* x16 = half ? reinterpret_cast<__bf16*>(e->x16) : nullptr;
   __bf16* x1_16 = half ? reinterpret_cast<__bf16*>(e->x1_16) : nullptr;
   __bf16* ctx16 = half ? reinterpret_cast<__bf16*>(e->ctx) : nullptr;
   hipLaunchKernelGGL(embed_ln_kernel, dim3((uint32_t)M), dim3(64), h * 4, st, e->d_ids,
                      has_tt ? e->d_tt : nullptr, (uint32_t)L, (uint32_t)h, c.vocab_size, c.type_vocab,
-                     e->word, e->pos, e->type, e->eln_w, e->eln_b, c.layer_norm_eps, e->x, e->d_flag, x16);
-  for (size_t li = 0; li < e->layers.size(); ++li) {
-    const auto& ly = e->layers[li];
-    if (half) launch_gemm_bf16<0, false, true, false>(x16, (const __bf16*)e->layers16[li].wqkv, ly.bqkv, nullptr, e->qkv, M, 3 * h, h, st);
+                     enc->word, enc->pos, enc->type, enc->eln_w, enc->eln_b, c.layer_norm_eps, e->x, e->d_flag, x16);
+  for (size_t li = 0; li < enc->layers.size(); ++li) {
+    const auto& ly = enc->layers[li];
+    if (half) launch_gemm_bf16<0, false, true, false>(x16, (const __bf16*)enc->layers16[li].wqkv, ly.bqkv, nullptr, e->qkv, M, 3 * h, h, st);
     else launch_gemm<0, false>(e->x, ly.wqkv, ly.bqkv, nullptr, e->qkv, M, 3 * h, h, st);
     dim3 ag((uint32_t)(B * c.heads), (uint32_t)((L + 63) / 64));
     if (dh == 64 && !valu_attention) hipLaunchKernelGGL(attention_mfma_kernel<64>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx, ctx16);
@@ -411,13 +468,13 @@ isl_status compute_forward(isl_encoder* e, bool has_tt, uint64_t B, uint64_t L, 
     else if (dh == 64) hipLaunchKernelGGL(attention_kernel<64>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
     else if (dh == 32) hipLaunchKernelGGL(attention_kernel<32>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
     else hipLaunchKernelGGL(attention_kernel<16>, ag, dim3(64), 0, st, e->qkv, e->d_mask, (uint32_t)L, c.heads, e->ctx);
-    if (half) launch_gemm_bf16<0, true, true, false>(ctx16, (const __bf16*)e->layers16[li].wo, ly.bo, e->x, e->t, M, h, h, st);
+    if (half) launch_gemm_bf16<0, true, true, false>(ctx16, (const __bf16*)enc->layers16[li].wo, ly.bo, e->x, e->t, M, h, h, st);
     else launch_gemm<0, true>(e->ctx, ly.wo, ly.bo, e->x, e->t, M, h, h, st);
     hipLaunchKernelGGL(ln_kernel, dim3((uint32_t)M), dim3(64), h * 4, st, e->t, (uint32_t)h, ly.ln1w, ly.ln1b, c.layer_norm_eps, e->x1, x1_16);
     if (half) {
-      if (c.gelu_tanh) launch_gemm_bf16<2, false, true, true>(x1_16, (const __bf16*)e->layers16[li].wi, ly.bi, nullptr, e->inter, M, I, h, st);
-      else launch_gemm_bf16<1, false, true, true>(x1_16, (const __bf16*)e->layers16[li].wi, ly.bi, nullptr, e->inter, M, I, h, st);
-      launch_gemm_bf16<0, true, true, false>(e->inter, (const __bf16*)e->layers16[li].wo2, ly.bo2, e->x1, e->t, M, h, I, st);
+      if (c.gelu_tanh) launch_gemm_bf16<2, false, true, true>(x1_16, (const __bf16*)enc->layers16[li].wi, ly.bi, nullptr, e->inter, M, I, h, st);
+      else launch_gemm_bf16<1, false, true, true>(x1_16, (const __bf16*)enc->layers16[li].wi, ly.bi, nullptr, e->inter, M, I, h, st);
+      launch_gemm_bf16<0, true, true, false>(e->inter, (const __bf16*)enc->layers16[li].wo2, ly.bo2, e->x1, e->t, M, h, I, st);
     } else {
       if (c.gelu_tanh) launch_gemm<2, false>(e->x1, ly.wi, ly.bi, nullptr, e->inter, M, I, h, st);
       else launch_gemm<1, false>(e->x1, ly.wi, ly.bi, nullptr, e->inter, M, I, h, st);
@@ -442,7 +499,7 @@ isl_status run_forward(isl_encoder* e, const int64_t* ids, const int64_t* tt, co
   if (tt) ISL_HIP(hipMemcpyAsync(e->d_tt, tt, M * 8, kind, st));
   if (mask) ISL_HIP(hipMemcpyAsync(e->d_mask, mask, M * 4, kind, st));
   else hipLaunchKernelGGL(fill_f32, dim3((uint32_t)((M + 255) / 256)), dim3(256), 0, st, e->d_mask, M, 1.0f);
-  return compute_forward(e, tt != nullptr, B, L, st);
+  return compute_forward(e, main_ws(e), tt != nullptr, B, L, st);
 }
 
 // token table row -> the int64 ids / f32 mask the model kernels read
@@ -460,11 +517,12 @@ __global__ void gather_tokens_kernel(const uint16_t* __restrict__ tokens, const 
   mask[i] = live ? 1.0f : 0.0f;
 }
 
-isl_status check_ids_flag(isl_encoder* e, hipStream_t st) {
-  uint32_t flag = 0;
+isl_status check_ids_flag(isl_encoder* e, hipStream_t st, bool side_too = false) {
+  uint32_t flag = 0, flag2 = 0;
   ISL_HIP(hipMemcpyAsync(&flag, e->d_flag, 4, hipMemcpyDeviceToHost, st));
+  if (side_too) ISL_HIP(hipMemcpyAsync(&flag2, e->side.d_flag, 4, hipMemcpyDeviceToHost, st));
   ISL_HIP(hipStreamSynchronize(st));
-  if (flag) return isl::fail(ISL_ERR_EMBEDDING, "Embedding error: token or token-type id out of range");
+  if (flag | flag2) return isl::fail(ISL_ERR_EMBEDDING, "Embedding error: token or token-type id out of range");
   return ISL_OK;
 }
 
@@ -496,16 +554,45 @@ isl_status encoder_embed_nodes(isl_encoder* e, const uint16_t* d_tokens, const u
                      L, e->cfg.max_position);
   std::lock_guard<std::mutex> lock(e->mu);
   const uint64_t chunk = 2048;  // sequences per model pass: (2048 x 64 tokens) x 3072 floats = 1.6 GB
-  ISL_TRY(ensure_ws(e, std::min(n, chunk), L));
-  for (uint64_t o = 0; o < n; o += chunk) {
-    const uint64_t B = std::min(chunk, n - o);
-    hipLaunchKernelGGL(gather_tokens_kernel, dim3((uint32_t)((B * L + 255) / 256)), dim3(256), 0, st, d_tokens,
-                       d_lens, L, d_node_ids + o, B, e->d_ids, e->d_mask);
-    ISL_TRY(compute_forward(e, false, B, L, st));
-    hipLaunchKernelGGL(pool_kernel, dim3((uint32_t)B), dim3(64), 0, st, e->x, e->d_mask, L,
+  // Two halves side by side (round 4).  One pass over B sequences runs its GEMMs as waves of 256 x 256 tiles, one
+  // workgroup per CU: 860 sequences x 64 tokens are 645 tiles of a hidden x hidden Linear = 2.52 waves, and the
+  // third wave leaves half the chip idle; LayerNorm, attention and the embedding gather (8 % of the time) leave
+  // the matrix cores idle altogether.  The halves of the batch go through the model on two streams with a
+  // workspace each: a CU that one half's GEMM has no tile left for takes the other half's workgroups, and one
+  // half's memory-bound kernels lie beside the other's GEMMs.  Same embeddings, bit for bit (every row is
+  // reduced in a fixed order that does not depend on the batch).  ISL_ENCODER_SPLIT=0: one pass (A/B switch,
+  // read per call).
+  const char* se = getenv("ISL_ENCODER_SPLIT");
+  const uint64_t split_min = se ? (uint64_t)std::max(0, atoi(se)) : 256;  // sequences from which a pass is split; 0 = never
+  auto half = [&](const EncWs& w, uint64_t o, uint64_t B, hipStream_t s) -> isl_status {
+    hipLaunchKernelGGL(gather_tokens_kernel, dim3((uint32_t)((B * L + 255) / 256)), dim3(256), 0, s, d_tokens,
+                       d_lens, L, d_node_ids + o, B, w.d_ids, w.d_mask);
+    ISL_TRY(compute_forward(e, w, false, B, L, s));
+    hipLaunchKernelGGL(pool_kernel, dim3((uint32_t)B), dim3(64), 0, s, w.x, w.d_mask, L,
                        (uint32_t)e->cfg.hidden, normalize, d_rows, d_out_rows + o, stride);
     ISL_HIP(hipGetLastError());
-    ISL_TRY(check_ids_flag(e, st));
+    return ISL_OK;
+  };
+  for (uint64_t o = 0; o < n; o += chunk) {
+    const uint64_t B = std::min(chunk, n - o);
+    if (split_min && B >= split_min && B >= 8) {
+      const uint64_t B0 = ((B / 2 + 3) / 4) * 4, B1 = B - B0;  // (whole 256-row tiles at 64 tokens per sequence)
+      ISL_TRY(ensure_ws(e, std::min(n, chunk), L));
+      ISL_TRY(ensure_side(e, (std::min(n, chunk) + 1) / 2, L));
+      hipStream_t side = (hipStream_t)e->side.stream;
+      ISL_HIP(hipEventRecord((hipEvent_t)e->side.ev_in, st));     // what the caller enqueued so far (the node lists)
+      ISL_HIP(hipStreamWaitEvent(side, (hipEvent_t)e->side.ev_in, 0));
+      isl_status rc = half(side_ws(e), o + B0, B1, side);
+      if (rc == ISL_OK) rc = half(main_ws(e), o, B0, st);
+      (void)hipEventRecord((hipEvent_t)e->side.ev_out, side);     // joined whatever happened: nothing stays behind on the side stream
+      (void)hipStreamWaitEvent(st, (hipEvent_t)e->side.ev_out, 0);
+      if (rc != ISL_OK) { (void)hipStreamSynchronize(st); return rc; }
+      ISL_TRY(check_ids_flag(e, st, true));
+    } else {
+      ISL_TRY(ensure_ws(e, std::min(n, chunk), L));
+      ISL_TRY(half(main_ws(e), o, B, st));
+      ISL_TRY(check_ids_flag(e, st));
+    }
   }
   return ISL_OK;
 }
@@ -521,6 +608,11 @@ void isl_encoder_free(isl_encoder* e) {
     void* ws[] = {e->x, e->x1, e->t, e->qkv, e->ctx, e->inter, e->d_mask, e->d_ids, e->d_tt, e->d_flag, e->x16, e->x1_16};
     for (void* p : ws)
       if (p) (void)hipFree(p);
+    free_side(e);
+    if (e->side.d_flag) (void)hipFree(e->side.d_flag);
+    if (e->side.ev_in) (void)hipEventDestroy((hipEvent_t)e->side.ev_in);
+    if (e->side.ev_out) (void)hipEventDestroy((hipEvent_t)e->side.ev_out);
+    if (e->side.stream) (void)hipStreamDestroy((hipStream_t)e->side.stream);
   }
   delete e;
 }

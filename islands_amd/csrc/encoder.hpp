@@ -26,6 +26,20 @@ struct isl_encoder {
   float* d_mask = nullptr;
   int64_t *d_ids = nullptr, *d_tt = nullptr;
   uint32_t* d_flag = nullptr;
+  // second workspace + stream (round 4): encoder_embed_nodes runs the two halves of a batch side by side,
+  // so that one half's last, partly filled wave of GEMM tiles and its LayerNorm / attention kernels lie
+  // beside the other half's GEMMs (a sequence's embedding does not depend on what it is batched with)
+  struct Side {
+    uint64_t ws_tokens = 0;
+    float *x = nullptr, *x1 = nullptr, *t = nullptr, *qkv = nullptr, *ctx = nullptr, *inter = nullptr;
+    void *x16 = nullptr, *x1_16 = nullptr;
+    float* d_mask = nullptr;
+    int64_t *d_ids = nullptr, *d_tt = nullptr;
+    uint32_t* d_flag = nullptr;
+    void* stream = nullptr;   // hipStream_t (non-blocking)
+    void* ev_in = nullptr;    // hipEvent_t: the caller's stream up to the call
+    void* ev_out = nullptr;   // hipEvent_t: the side stream's half is done
+  } side;
   std::mutex mu;
 };
 

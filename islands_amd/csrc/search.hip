@@ -561,10 +561,6 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
   p.q_evals = nullptr;
   static const uint32_t seq_max_env = [] { const char* e = getenv("ISL_SEQ_MAX"); return e ? (uint32_t)atoi(e) : 0u; }();
   p.seq_max = seq_max_env;
-  {  // ISL_AGE_PRIO=h: waves raise their priority every h expansions of their query (read per call: A/B in one process)
-    const char* e = getenv("ISL_AGE_PRIO");
-    p.age_prio = e ? (uint32_t)std::max(0, atoi(e)) : 0u;
-  }
   if (tl) {
     const isl_pq* pq = idx->pq;
     const uint64_t want = std::max<uint64_t>(nq, 1) * pq->m * pq->K;

@@ -117,9 +117,6 @@ struct SearchParams {
   uint32_t tl_m, tl_K;
   float tl_ratio;
   uint32_t tl_wcap;           // entries of the approximate queue kept in LDS (multiple of 64)
-  // oldest first: a query's wave raises its issue priority (s_setprio 1, 2, 3) after age_prio, 2 x, 3 x
-  // age_prio expansions; 0 = off.  Results do not depend on it.
-  uint32_t age_prio;
 };
 
 // ------------------------------------------------------------- sorted result set
@@ -665,8 +662,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void le
       continue;
     }
     const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
-    uint32_t next_age = p.age_prio;
-    if (p.age_prio) __builtin_amdgcn_s_setprio(0);
     bool resumed = false;
     uint32_t* qst = nullptr;
     if constexpr (RESUME) {
@@ -797,13 +792,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void le
       }
       cH += 1;
       cE += deg;
-      if (p.age_prio && cH == next_age) {  // oldest first (wave-uniform): long queries are what a batch waits for
-        const uint32_t lvl = cH / p.age_prio;
-        if (lvl == 1) __builtin_amdgcn_s_setprio(1);
-        else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
-        else __builtin_amdgcn_s_setprio(3);
-        next_age = lvl < 3 ? next_age + p.age_prio : 0xFFFFFFFFu;
-      }
       if (deg == 0) continue;
       if (deg > kMaxDeg) { status = QS_REDO; payload = 1; break; }  // long rows: exact kernel
       bool active = (uint32_t)lane < deg;

@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--quantum-ab", action="store_true",
                     help="run the searches twice: with every miss of a round encoded at once (ISL_RECOMPUTE_QUANTUM=0, "
                          "rounds 1-3's behaviour) and with the rounds' encoder batches in whole waves of GEMM tiles")
+    ap.add_argument("--split-ab", action="store_true",
+                    help="run the searches with the encoder's passes whole (ISL_ENCODER_SPLIT=0) and as two halves side by "
+                         "side on two streams (default), each with and without the whole-tile-wave quantum, twice")
     ap.add_argument("--check-in-memory", action="store_true",
                     help="also run the batch over the in-memory provider holding the same embeddings and compare bits")
     args = ap.parse_args()
@@ -261,6 +264,24 @@ def main():
         log(f"{label}: ef={ef} ratio={tl_ratio}: recall {res['recall_at_10']}, {dt:.1f}s, {res['encoded_nodes_per_query']} nodes/query")
         return res
 
+    if args.split_ab:
+        import os
+        for rep in range(2):
+            for split, quantum in (("0", None), (None, None), (None, "0"), ("0", "0")):
+                for var, val in (("ISL_ENCODER_SPLIT", split), ("ISL_RECOMPUTE_QUANTUM", quantum)):
+                    if val is None:
+                        os.environ.pop(var, None)
+                    else:
+                        os.environ[var] = val
+                label = (f"encoder passes {'whole' if split == '0' else 'as two halves side by side'}, "
+                         f"batches {'every miss at once' if quantum == '0' else 'in whole tile waves'}")
+                if pq is not None:
+                    run(f"two_level, {label}", qh, tih, ef_tl, ratio, check=True)
+                else:
+                    run(f"plain, {label}", qh, tih, efs[0], 0.0, check=args.check_in_memory)
+        os.environ.pop("ISL_ENCODER_SPLIT", None)
+        os.environ.pop("ISL_RECOMPUTE_QUANTUM", None)
+        return
     if args.quantum_ab:
         import os
         for label, env in (("every miss at once", "0"), ("whole tile waves", None), ("every miss at once", "0"),

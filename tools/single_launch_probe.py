@@ -34,7 +34,9 @@ def main():
     ap.add_argument("--nq", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--age-prio", default="", help="comma list of ISL_AGE_PRIO settings (0 = off) to run every leg under, "
-                    "interleaved in one process: waves raise their issue priority every h expansions of their query")
+                    "interleaved in one process: waves raise their issue priority every h expansions of their query "
+                    "(needs the kernel of commit 18c59ad, which read that variable: measured without effect, "
+                    "profiles/r04_age_prio_probe.json, and taken out again)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     N, d, nq, k, ef, B = a.nodes, a.dim, a.nq, 10, 128, a.batches

@@ -108,6 +108,30 @@ def make_uniform(count: int, d: int, seed: int, device="cuda:0", start: int = 0)
     return out
 
 
+def make_manifold(count: int, d: int, seed: int, device="cuda:0", start: int = 0, latent: int = 16,
+                  noise: float = 0.1) -> torch.Tensor:
+    """Dataset M: rows on a low-dimensional linear manifold, x = normalise(z W + noise * g) with z ~ N(0, I_latent),
+    W a fixed [latent, d] matrix with N(0, 1 / latent) entries and g ~ N(0, I_d) -- no clusters, no tree, one smooth
+    density of intrinsic dimension `latent` (what learned embeddings look like to a proximity graph far more than
+    i.i.d. uniform rows in 768 dimensions, which no ANN index can navigate).  Nothing here knows about any graph
+    builder.  Rows [start, start + count) of the stream `seed` names, chunk-seeded like the other datasets."""
+    dev = torch.device(device)
+    gw = torch.Generator(device=dev)
+    gw.manual_seed(977)
+    W = torch.randn((latent, d), generator=gw, device=dev, dtype=torch.float32) / math.sqrt(latent)
+    out = torch.empty((count, d), device=dev, dtype=torch.float32)
+    g = torch.Generator(device=dev)
+    for c in range(start // CHUNK, (start + count + CHUNK - 1) // CHUNK):
+        lo, hi = c * CHUNK, (c + 1) * CHUNK
+        g.manual_seed(seed * 1000003 + c * 7919 + 23)
+        z = torch.randn((CHUNK, latent), generator=g, device=dev, dtype=torch.float32)
+        x = z @ W + noise * torch.randn((CHUNK, d), generator=g, device=dev, dtype=torch.float32)
+        x = x / x.norm(dim=1, keepdim=True)
+        a, b = max(lo, start), min(hi, start + count)
+        out[a - start:b - start] = x[a - lo:b - lo]
+    return out
+
+
 # ------------------------------------------------------------------ ground truth
 @torch.no_grad()
 def brute_force_topk(x: torch.Tensor, q: torch.Tensor, k: int, metric: str = "cosine",
