@@ -554,16 +554,20 @@ isl_status encoder_embed_nodes(isl_encoder* e, const uint16_t* d_tokens, const u
                      L, e->cfg.max_position);
   std::lock_guard<std::mutex> lock(e->mu);
   const uint64_t chunk = 2048;  // sequences per model pass: (2048 x 64 tokens) x 3072 floats = 1.6 GB
-  // Two halves side by side (round 4).  One pass over B sequences runs its GEMMs as waves of 256 x 256 tiles, one
-  // workgroup per CU: 860 sequences x 64 tokens are 645 tiles of a hidden x hidden Linear = 2.52 waves, and the
-  // third wave leaves half the chip idle; LayerNorm, attention and the embedding gather (8 % of the time) leave
-  // the matrix cores idle altogether.  The halves of the batch go through the model on two streams with a
-  // workspace each: a CU that one half's GEMM has no tile left for takes the other half's workgroups, and one
-  // half's memory-bound kernels lie beside the other's GEMMs.  Same embeddings, bit for bit (every row is
-  // reduced in a fixed order that does not depend on the batch).  ISL_ENCODER_SPLIT=0: one pass (A/B switch,
-  // read per call).
+  // Two halves side by side (round 4, opt-in: ISL_ENCODER_SPLIT=<sequences from which a pass is split>).  One pass
+  // over B sequences runs its GEMMs as waves of 256 x 256 tiles, one workgroup per CU: 860 sequences x 64 tokens are
+  // 645 tiles of a hidden x hidden Linear = 2.52 waves, and the third wave leaves half the chip idle; LayerNorm,
+  // attention and the embedding gather (8 % of the time) leave the matrix cores idle altogether.  Here the halves
+  // of the batch go through the model on two streams with a workspace each: a CU that one half's GEMM has no tile
+  // left for takes the other half's workgroups, one half's memory-bound kernels lie beside the other's GEMMs.
+  // Same embeddings, bit for bit (every row is reduced in a fixed order that does not depend on the batch).
+  // MEASURED (config 3 at 1M nodes, 256 queries, ~500 misses per round; profiles/r04_recompute_1m_split_ab.jsonl,
+  // all four settings interleaved in one process): whole passes 34.4 queries/s, halves side by side 35.4, whole
+  // passes over batches cut to whole tile waves (assign_slots_kernel's quantum) 35.6, both 35.4 -- the two remedies
+  // recover the same idle wave and do not add up; the quantum needs no second workspace, so it is the default and
+  // this stays a switch (read per call).
   const char* se = getenv("ISL_ENCODER_SPLIT");
-  const uint64_t split_min = se ? (uint64_t)std::max(0, atoi(se)) : 256;  // sequences from which a pass is split; 0 = never
+  const uint64_t split_min = se ? (uint64_t)std::max(0, atoi(se)) : 0;  // 0 = never
   auto half = [&](const EncWs& w, uint64_t o, uint64_t B, hipStream_t s) -> isl_status {
     hipLaunchKernelGGL(gather_tokens_kernel, dim3((uint32_t)((B * L + 255) / 256)), dim3(256), 0, s, d_tokens,
                        d_lens, L, d_node_ids + o, B, w.d_ids, w.d_mask);

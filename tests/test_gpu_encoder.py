@@ -240,6 +240,40 @@ def test_recompute_rounds_encode_in_quanta_and_answer_the_same(orc, monkeypatch)
     assert runs[("100", None)]["encoded_nodes"] == runs[("0", None)]["encoded_nodes"]
 
 
+def test_recompute_encoder_passes_split_in_two_answer_the_same(orc, monkeypatch):
+    """encoder_embed_nodes runs the two halves of a pass side by side on two streams with a workspace each
+    (ISL_ENCODER_SPLIT = the batch size from which it does; unset or 0 = never): the embeddings, and with them every
+    answer, distance bit and counter, are those of the whole pass and of the in-memory provider."""
+    cfg, enc, tok, lens, emb = _recompute_case(orc, n=1600, seed=23, min_len=5)
+    n = emb.shape[0]
+    from _data import random_csr
+    q = emb[::17] + np.float32(0.015)
+    off, nb = random_csr(n, 30, 9)
+    csr = orc.Csr(off, nb, entry_point=11)
+    g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels, entry_point=11,
+                    num_nodes=n, degree_counts=csr.degree_counts)
+    mem_idx = ia.LeannIndex.from_csr(g, None, dimension=64).upload(0)
+    mem_idx.set_embeddings(emb)
+    want = mem_idx.search_batch(q, 10, 96)
+    want_stats = mem_idx.last_stats()
+    encoded = {}
+    for split in ("0", "8", "50", "256", None):
+        if split is None:
+            monkeypatch.delenv("ISL_ENCODER_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("ISL_ENCODER_SPLIT", split)
+        rec_idx = ia.LeannIndex.from_csr(g, None, dimension=64).upload(0)
+        rec_idx.set_recompute_provider(enc, tok, lens)
+        got = rec_idx.search_batch(q, 10, 96)
+        st = rec_idx.last_stats()
+        assert got[0].tolist() == want[0].tolist() and got[2].tolist() == want[2].tolist(), split
+        assert got[1].view(np.uint32).tolist() == want[1].view(np.uint32).tolist(), split
+        for f in ("expansions", "edges", "evals", "pushes"):
+            assert st[f] == want_stats[f], (f, split)
+        encoded[split] = st["encoded_nodes"]
+    assert len(set(encoded.values())) == 1
+
+
 def test_recompute_provider_keeps_rows_when_asked(orc):
     cfg, enc, tok, lens, emb = _recompute_case(orc, n=400, seed=9)
     levels = np.zeros(400, np.uint64)

@@ -186,11 +186,12 @@ def main():
         log(f"PQ m={args.pq_m} trained, {N} rows encoded in {time.time() - t0:.1f}s")
     efs = [int(e) for e in args.ef_list.split(",") if e] or [args.ef]
     ef_tl, sweep = efs[0], None
-    if args.two_level_auto:
+    if pq is not None and midx is not None:
         midx.set_pq_codes(pq, None, device_ptr=codes.data_ptr(), n=N)
+    if args.two_level_auto:
         sweep = []
-        for efv in sorted(set(efs + [128, 192, 256, 384])):
-            for a_ in (0.05, 0.1, 0.15, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 1.0):
+        for efv in sorted(set(efs + [128, 192, 224, 256, 320, 384])):
+            for a_ in (0.01, 0.02, 0.03, 0.05, 0.1, 0.15, 0.2, 0.3, 0.5, 0.7, 1.0):
                 ids, dist, cnt = midx.search_two_level_batch(qh, args.k, efv, a_)
                 st = midx.last_stats()
                 sweep.append({"ef": efv, "ratio": a_, "recall_at_10": round(recall_of(ids, cnt), 4),
@@ -267,7 +268,7 @@ def main():
     if args.split_ab:
         import os
         for rep in range(2):
-            for split, quantum in (("0", None), (None, None), (None, "0"), ("0", "0")):
+            for split, quantum in (("0", None), ("256", None), ("256", "0"), ("0", "0")):
                 for var, val in (("ISL_ENCODER_SPLIT", split), ("ISL_RECOMPUTE_QUANTUM", quantum)):
                     if val is None:
                         os.environ.pop(var, None)
