@@ -109,6 +109,7 @@ struct SearchWorkspace {
   uint32_t* uniq = nullptr;
   uint32_t* uniq_count = nullptr;
   uint64_t miss_cap = 0;
+  uint64_t pref_cap = 0;         // entries behind miss[miss_cap]: ids a parked two-level query expects to promote next
   // ... and, for the searches that park and resume (fast kernel over the recompute provider): the
   // parked state of every query, its flag, the list of queries a round runs
   uint32_t* qstate = nullptr;
@@ -126,6 +127,7 @@ struct SearchWorkspace {
   // all queries; otherwise the RESUME kernel over `round_active` queries, listed in qlist unless
   // it is the first round
   uint32_t round_active = 0;
+  uint32_t round_prefetch = 0;  // two-level search: ids a parked query names beyond its misses (0 = none)
   bool round_listed = false;
   // two-level search: per-query PQ distance tables [nq][m * K]
   float* tl_tables = nullptr;

@@ -112,6 +112,7 @@ __global__ void seed_redo_kernel(const uint32_t* __restrict__ list, uint32_t n, 
 }
 
 constexpr uint32_t kExactSlots = 32;
+constexpr uint32_t kTlPrefetchDefault = 0;  // (set from the measurement: DESIGN.md section 3.4)
 constexpr uint32_t kOvfBits = 15;
 constexpr uint32_t kMaxExactEf = 4096;
 
@@ -553,6 +554,9 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
   }
   p.miss = ws.miss;
   p.miss_cap = (uint32_t)std::min<uint64_t>(ws.miss_cap, 0xFFFFFFFFull);
+  p.pref = ws.miss ? ws.miss + ws.miss_cap : nullptr;
+  p.pref_cap = (uint32_t)ws.pref_cap;
+  p.tl_prefetch = (tl && resume && ws.pref_cap) ? ws.round_prefetch : 0u;
   p.layer_off = idx->d_layer_off;
   p.layer_adj = idx->d_layer_adj;
   p.max_level = idx->is_hnsw ? (uint32_t)idx->max_level : 0u;
@@ -964,17 +968,20 @@ isl_status tl_collect_short(isl::SearchWorkspace& ws, uint64_t nq, uint32_t* cou
 
 isl_status prepare_recompute(isl::SearchWorkspace& ws, uint64_t nq, uint64_t state_words_per_query) {
   const uint64_t cap = std::min<uint64_t>(nq * 128 + 64, 0xFFFFFFF0ull);  // a hop keeps up to 128 rows
-  if (ws.miss_cap < cap) {
+  const uint64_t pcap = nq * 8 + 64;  // + the ids parked two-level queries expect to promote next (behind miss[cap])
+  if (ws.miss_cap < cap || ws.pref_cap < pcap) {
     void* ptrs[] = {ws.miss, ws.uniq, ws.uniq_count, ws.uslots};
     for (void* q : ptrs)
       if (q) (void)hipFree(q);
     ws.miss = ws.uniq = ws.uniq_count = ws.uslots = nullptr;
     ws.miss_cap = 0;
-    ISL_TRY(lane_malloc(ws, ws.miss, cap * 4));
-    ISL_TRY(lane_malloc(ws, ws.uniq, cap * 4));
-    ISL_TRY(lane_malloc(ws, ws.uslots, cap * 4));
+    ws.pref_cap = 0;
+    ISL_TRY(lane_malloc(ws, ws.miss, (cap + pcap) * 4));
+    ISL_TRY(lane_malloc(ws, ws.uniq, (cap + pcap) * 4));
+    ISL_TRY(lane_malloc(ws, ws.uslots, (cap + pcap) * 4));
     ISL_TRY(lane_malloc(ws, ws.uniq_count, 4));
     ws.miss_cap = cap;
+    ws.pref_cap = pcap;
   }
   ISL_TRY(ensure_qlist(ws, nq));
   ISL_TRY(ensure(ws, ws.qstate, ws.qstate_words, std::max<uint64_t>(nq, 1) * state_words_per_query));
@@ -1090,6 +1097,7 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
     hipStream_t st;
     ~RoundReset() {
       w.round_active = 0;
+      w.round_prefetch = 0;
       w.round_x = 0;
       w.round_xpark = false;
       w.round_listed = false;
@@ -1109,16 +1117,24 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
   // through in, so a 256-row cache (one query at a time) is not cut short and a bug still ends.
   const uint64_t max_rounds = 64 + ((nq + max_active - 1) / max_active) * ((uint64_t)64 * cg0.ef + 4096);
   uint32_t stalled = 0;
+  // Two-level search: a parked query also names the nodes it expects to promote next (tl_prefetch of them), which
+  // are encoded in the same round -- fewer, fuller rounds.  Only with a slab that has room to spare (the names are
+  // guesses: under a small cache they would push out rows that hops are waiting for).  ISL_TL_PREFETCH=n overrides
+  // (0 = off; read per call).
+  uint32_t prefetch = (tl && idx->slab_rows >= (uint64_t)1024 * std::max<uint32_t>(1u, max_active)) ? kTlPrefetchDefault : 0u;
+  if (const char* pe = getenv("ISL_TL_PREFETCH")) prefetch = tl ? (uint32_t)std::min(8, std::max(0, atoi(pe))) : 0u;
   std::vector<uint32_t> again;  // two-level search: queries to start over with a larger queue window
   for (;;) {
     ws.round_active = active;
     ws.round_x = nxl;
     ws.round_xpark = x_park;
     ws.round_listed = listed;
+    ws.round_prefetch = prefetch;
     idx->round_no += 1;
     ISL_TRY(search_enqueue(idx, ws, d_queries, nq, d, k, ef, d_ids, d_dist, d_count, user_stream, mode, tl));
     uint32_t misses = 0;
     ISL_TRY(search_finish(idx, ws, &misses, nullptr, resumable));
+    const uint32_t guesses = prefetch ? std::min<uint32_t>(ws.h_head[14], (uint32_t)ws.pref_cap) : 0u;
     kernel_ms += ws.stats.kernel_ms;
     rounds += 1;
     if (resumable) {  // next round: the queries that are waiting for rows, topped up with fresh ones
@@ -1173,6 +1189,10 @@ isl_status search_sync(const isl_index* idx, isl::SearchWorkspace& ws, const flo
     ISL_HIP(hipMemsetAsync(ws.uniq_count, 0, 4, st));
     hipLaunchKernelGGL(dedupe_misses_kernel, dim3((misses + 255) / 256), dim3(256), 0, st, ws.miss, misses,
                        idx->d_slot_of, ws.uniq, ws.uniq_count);
+    // the guesses go behind the misses in the unique list: what a full slab or the quantum leaves out is theirs first
+    if (guesses)
+      hipLaunchKernelGGL(dedupe_misses_kernel, dim3((guesses + 255) / 256), dim3(256), 0, st, ws.miss + ws.miss_cap, guesses,
+                         idx->d_slot_of, ws.uniq, ws.uniq_count);
     // slots for the new rows (clock hand over the slab; rows asked for in this round stay)
     hipLaunchKernelGGL(assign_slots_kernel, dim3(1), dim3(64), 0, st, ws.uniq, ws.uniq_count, idx->round_no,
                        (uint32_t)idx->slab_rows, idx->d_slab_head, idx->d_slot_of, idx->d_owner, idx->d_stamp,

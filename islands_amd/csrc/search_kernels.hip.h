@@ -117,6 +117,12 @@ struct SearchParams {
   uint32_t tl_m, tl_K;
   float tl_ratio;
   uint32_t tl_wcap;           // entries of the approximate queue kept in LDS (multiple of 64)
+  // recompute provider, two-level search: a query that parks on an absent row also names the next tl_prefetch
+  // unpromoted entries of its queue past the promoted prefix (count in ticket[14], list in pref) -- the nodes
+  // it will most likely promote in its next hops, encoded in the same round.  Answers do not depend on it.
+  uint32_t tl_prefetch;
+  uint32_t* pref;
+  uint32_t pref_cap;
 };
 
 // ------------------------------------------------------------- sorted result set
@@ -1788,6 +1794,25 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
             for (uint32_t i = lane; i < wlen; i += 64) swin[i] = win[i];
             for (uint32_t i = lane; i < hcap; i += 64) qst[16 + 2 * resn + 2 * (wcap + 64) + i] = htab[i];
             parked = true;
+          }
+          if constexpr (RESUME) {
+            if (p.tl_prefetch) {  // what this query will most likely ask for next: the queue's entries right behind the prefix
+              const uint32_t i = ntop + lane;
+              const uint64_t x = i < wlen ? win[i] : ~0ull;
+              const bool un = i < wlen && !(x & 1ull);
+              const uint64_t um = ballot(un);
+              const uint32_t r0 = (uint32_t)__popcll(um & ((1ull << lane) - 1ull));
+              const uint32_t fid = (uint32_t)(x >> 1) & ID_MASK;
+              const bool want = un && r0 < p.tl_prefetch && (uint64_t)fid < p.nvec && p.slot_of[fid] == kNoSlot;
+              const uint64_t wm = ballot(want);
+              if (wm) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&p.ticket[14], (uint32_t)__popcll(wm));
+                base = uni(base);
+                const uint32_t r1 = (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
+                if (want && base + r1 < p.pref_cap) p.pref[base + r1] = fid;
+              }
+            }
           }
           break;
         }

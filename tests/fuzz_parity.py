@@ -269,9 +269,20 @@ def recompute_case(rng, case):
     # bounded row cache like the others -- before, it needed its whole traversal resident)
     rows = int(rng.choice([256, max(256, n // 3), n]))
     keep = bool(rng.random() < 0.3)
+    # round 4: the rounds' encoder batches cut to whole waves of GEMM tiles (left-over misses reported again) and the
+    # encoder's passes as two halves side by side -- any quantum, any split threshold, the same answers
+    quantum = rng.choice(["", "0", "8", "37", "100"])
+    split = rng.choice(["", "0", "8", "40"])
+    ahead = rng.choice(["", "0", "3", "8"])  # two-level search: nodes a parked query names beyond its misses
+    for var, val in (("ISL_RECOMPUTE_QUANTUM", quantum), ("ISL_ENCODER_SPLIT", split), ("ISL_TL_PREFETCH", ahead)):
+        if val == "":
+            os.environ.pop(var, None)
+        else:
+            os.environ[var] = str(val)
     rec = ia.LeannIndex.from_csr(g, cfg, dimension=emb.shape[1]).upload(0)
     rec.set_recompute_provider(enc, tok, lens, keep_rows=keep, cache_rows=rows)
-    desc = f"case {case}: n={n} L={L} deg={deg} metric={metric} ef={ef} k={k} nq={nq} rows={rows} keep={keep} ties={ties}"
+    desc = (f"case {case}: n={n} L={L} deg={deg} metric={metric} ef={ef} k={k} nq={nq} rows={rows} keep={keep} ties={ties} "
+            f"quantum={quantum!r} split={split!r} ahead={ahead!r}")
     for rep in range(2):
         got = rec.search_batch(q, k, ef)
         st = rec.last_stats()

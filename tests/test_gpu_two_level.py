@@ -312,6 +312,33 @@ def test_two_level_recompute_parks_and_resumes_with_a_small_row_cache(orc):
     del pq
 
 
+def test_two_level_recompute_names_the_nodes_it_will_promote_next(orc, monkeypatch):
+    """ISL_TL_PREFETCH=n: a query that parks on an absent row also names the next n unpromoted entries of its
+    queue, which the provider encodes in the same round -- fewer rounds, some nodes encoded that are never
+    asked for, and every id, distance bit and counter of the answers unchanged (with a row for every node and
+    with a cache that turns over)."""
+    for cache_rows in (None, 512):
+        emb, csr, cb, codes, mem_idx, rec_idx, pq, enc = _recompute_pair(orc, cache_rows=cache_rows)
+        q = emb[::41] + np.float32(0.02)
+        rounds = {}
+        for (k, ef, ratio) in ((10, 64, 0.1), (10, 200, 0.05), (5, 100, 0.4)):
+            want = mem_idx.search_two_level_batch(q, k, ef, ratio)
+            want_stats = mem_idx.last_stats()
+            for n in ("0", "2", "8"):
+                monkeypatch.setenv("ISL_TL_PREFETCH", n)
+                got = rec_idx.search_two_level_batch(q, k, ef, ratio)
+                st = rec_idx.last_stats()
+                assert got[2].tolist() == want[2].tolist() and got[0].tolist() == want[0].tolist(), (k, ef, ratio, n)
+                assert got[1].view(np.uint32).tolist() == want[1].view(np.uint32).tolist(), (k, ef, ratio, n)
+                for f in ("expansions", "edges", "evals", "pushes"):
+                    assert st[f] == want_stats[f], (f, k, ef, ratio, n)
+                rounds[(k, ef, ratio, n)] = (st["recompute_rounds"], st["encoded_nodes"])
+            if cache_rows is None:  # nothing is evicted: naming nodes ahead can only save rounds and only add encodes
+                assert rounds[(k, ef, ratio, "8")][0] <= rounds[(k, ef, ratio, "0")][0]
+                assert rounds[(k, ef, ratio, "8")][1] >= rounds[(k, ef, ratio, "0")][1]
+        del pq
+
+
 def test_two_level_async_calls_overlap_and_retry(orc):
     """isl_search_two_level_batch_device_async: several calls in flight on the index's lanes, each
     completed by its token with its own counters; one of them needs the window retry."""

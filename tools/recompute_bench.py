@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--split-ab", action="store_true",
                     help="run the searches with the encoder's passes whole (ISL_ENCODER_SPLIT=0) and as two halves side by "
                          "side on two streams (default), each with and without the whole-tile-wave quantum, twice")
+    ap.add_argument("--prefetch-ab", default="", metavar="LIST",
+                    help="two-level search: run it under ISL_TL_PREFETCH = each value of the comma list (nodes a parked "
+                         "query names beyond its misses; 0 = none), twice, interleaved in one process")
     ap.add_argument("--check-in-memory", action="store_true",
                     help="also run the batch over the in-memory provider holding the same embeddings and compare bits")
     args = ap.parse_args()
@@ -265,6 +268,14 @@ def main():
         log(f"{label}: ef={ef} ratio={tl_ratio}: recall {res['recall_at_10']}, {dt:.1f}s, {res['encoded_nodes_per_query']} nodes/query")
         return res
 
+    if args.prefetch_ab and pq is not None:
+        import os
+        for rep in range(2):
+            for v in args.prefetch_ab.split(","):
+                os.environ["ISL_TL_PREFETCH"] = v
+                run(f"two_level, {v} nodes named ahead per parked query", qh, tih, ef_tl, ratio, check=True)
+        os.environ.pop("ISL_TL_PREFETCH", None)
+        return
     if args.split_ab:
         import os
         for rep in range(2):

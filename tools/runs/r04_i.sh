@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 4, GPU call I: two-level search over the recompute provider naming nodes ahead (tests, then config 3 at 1M, A/B in one process)
+set -o pipefail
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout -k 10 600 python -m pytest tests/test_gpu_encoder.py tests/test_gpu_two_level.py -m gpu -x -q > gpurun_out/r04_i_tests.log 2>&1 || { tail -30 gpurun_out/r04_i_tests.log; exit 1; }
+tail -2 gpurun_out/r04_i_tests.log
+timeout -k 10 900 python tools/recompute_bench.py --nodes 1000000 --nq 256 --ef 128 --two-level 0.05 --pq-m 192 --check-in-memory --prefetch-ab 0,1,2,4,8 > gpurun_out/r04_recompute_1m_prefetch_ab.jsonl 2> gpurun_out/r04_recompute_1m_prefetch_ab.err || { tail -20 gpurun_out/r04_recompute_1m_prefetch_ab.err; exit 1; }
+python3 - <<'PY'
+import json
+for l in open("gpurun_out/r04_recompute_1m_prefetch_ab.jsonl"):
+    if l.startswith("{"):
+        d = json.loads(l)
+        print({k: d.get(k) for k in ("run", "value", "seconds", "rounds", "encoded_nodes", "recall_at_10", "equals_in_memory_provider")}, d.get("roofline", {}).get("frac"))
+PY
