@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -200,6 +201,9 @@ struct isl_index {
   uint32_t* d_adj = nullptr;  // [nnz] (duplicates within a row removed, first occurrence kept)
   uint64_t nnz = 0;
   uint32_t max_degree = 0;
+  // distance evaluations per query of the most recent in-memory search call (0 = none yet): the size of the
+  // visited table follows it (search.hip, fast_geometry)
+  mutable std::atomic<uint32_t> evals_hint{0};
   // in-memory provider (leann.rs:104-159): nvec rows, `stride` floats apart
   float* d_emb = nullptr;
   uint16_t* d_emb16 = nullptr;  // bf16 rows (ISL_DTYPE_BF16) instead of d_emb

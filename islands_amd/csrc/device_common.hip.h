@@ -61,6 +61,10 @@ __device__ __forceinline__ uint32_t ordkey(float d) {
 __device__ __forceinline__ uint32_t hslot(uint32_t id, uint32_t bits) {
   return (id * 0x9E3779B1u) >> (32u - bits);
 }
+// the same for a table of any size: the top of the 64-bit product (cap = 1 << bits gives hslot's value)
+__device__ __forceinline__ uint32_t hslot_cap(uint32_t id, uint32_t cap) {
+  return __umulhi(id * 0x9E3779B1u, cap);
+}
 
 // apply_pruning_strategy, leann.rs:991-1016: Global/Local keep a prefix.
 // Proportional (thread_rng, leann.rs:1043) takes the deterministic fallback `take(num_to_keep)`.

@@ -27,13 +27,16 @@
 namespace {
 
 struct FastGeom {
-  uint32_t hbits;
+  uint32_t hbits;  // the table ef (and a long query) alone give: 1 << hbits entries; what parked queries' state blocks hold
   size_t lds;
+  uint32_t hcap;   // entries of the table this launch runs with (1 << hbits unless the index's hint enlarged it)
 };
 
 // qbytes = bytes per query element in LDS: 4, or 2 for the instantiation that keeps a bf16-valued
 // query as bf16 (bf16 rows; at d = 4096 the query is what bounds the waves per CU)
-FastGeom fast_geometry(uint32_t ef, uint32_t d, uint32_t qbytes = 4) {
+// vhint = distance evaluations per query this index's searches have been making (0 = unknown): every
+// evaluated node is an entry of the visited table.
+FastGeom fast_geometry(uint32_t ef, uint32_t d, uint32_t qbytes = 4, uint32_t vhint = 0) {
   // visited capacity grows with ef (V is roughly 10-30 x ef); overflow goes to HBM
   uint32_t hbits = ef <= 64 ? 10 : ef <= 160 ? 11 : ef <= 320 ? 12 : 13;
   static const int hbits_env = [] { const char* e = getenv("ISL_HBITS"); return e ? atoi(e) : 0; }();
@@ -43,13 +46,43 @@ FastGeom fast_geometry(uint32_t ef, uint32_t d, uint32_t qbytes = 4) {
   // ef = 128: 0.40 -> 0.45 of the HBM peak).  At d = 768 the full table wins and stays.
   const size_t qlds = (size_t)d * qbytes;
   if (qlds >= ((size_t)4 << hbits) && hbits > 9) hbits -= 1;
-  if (hbits_env >= 8 && hbits_env <= 14) hbits = (uint32_t)hbits_env;  // experiments only
   // visited table, merge buffer, query (+ 64 bytes when d is not a multiple of 16: the operand
   // prefetch of direct_group may touch the rest of the last step)
-  size_t lds = ((size_t)4 << hbits) + (size_t)mbuf_entries(ef) * 8 +
-               (qbytes == 2 ? (size_t)((d + 7) / 8 * 8) * 2 + 64 : (size_t)((d + 3) / 4 * 4) * 4 + ((d & 15) ? 64 : 0));
-  return {hbits, lds};
+  const size_t rest = (size_t)mbuf_entries(ef) * 8 +
+                      (qbytes == 2 ? (size_t)((d + 7) / 8 * 8) * 2 + 64 : (size_t)((d + 3) / 4 * 4) * 4 + ((d & 15) ? 64 : 0));
+  if (hbits_env >= 8 && hbits_env <= 14) hbits = (uint32_t)hbits_env;  // experiments only
+  uint32_t hcap = 1u << hbits;
+  // Round 4: a larger table when the index's queries have been filling it past its 7/8 limit on average.
+  // How many nodes a query evaluates is a property of the graph and the data, not of ef alone (ef = 128: 1226
+  // on the tree-of-clusters rows with the harness graph, 3100-3400 on manifold rows with an exact-kNN graph),
+  // and a query past the limit pays an atomic round trip to its HBM overflow table for every further hop:
+  // measured on the latter rows (1M x 768, 20 steps, profiles/r04_bench_M_knn_1m_hbits{11,12,13}.json)
+  // 2048 entries 558 k queries/s, 4096 entries 686 k (12 -> 7 waves per CU and still +23 %), 8192 entries 602 k.
+  // The table need not be a power of two (hslot_cap): it takes what the average query needs, in steps of 512
+  // entries and at most twice the default, and then whatever else fits beside the same number of waves per CU.
+  static const bool no_hint = getenv("ISL_NO_VISITED_HINT") != nullptr;  // A/B switch for measurements
+  static const int hcap_env = [] { const char* e = getenv("ISL_HCAP"); return e ? atoi(e) : 0; }();  // experiments only
+  if (vhint && !no_hint && hbits_env == 0) {
+    const uint64_t need = ((uint64_t)vhint * 8 + 6) / 7;
+    if (need > hcap) {
+      const uint64_t most = (uint64_t)2 << hbits;
+      uint64_t want = std::min<uint64_t>((need + 511) / 512 * 512, most);
+      auto lds_of = [&](uint64_t cap) { return (cap * 4 + rest + 511) / 512 * 512; };  // (LDS is handed out in 512-byte granules)
+      auto room = [&](size_t waves) -> uint64_t {  // the largest table that leaves `waves` waves per CU
+        const size_t each = (160 * 1024) / waves / 512 * 512;
+        return each > rest ? std::min<uint64_t>((each - rest) / 4 / 64 * 64, most) : 0;
+      };
+      const size_t per_cu = std::max<size_t>(1, (160 * 1024) / lds_of(want));
+      want = std::max(want, room(per_cu));           // what fits beside the same waves is free
+      if (room(per_cu + 1) >= need) want = room(per_cu + 1);  // one more wave per CU if the average query still fits
+      hcap = (uint32_t)want;
+    }
+  }
+  if (hcap_env >= 256 && hcap_env <= 16384) hcap = (uint32_t)hcap_env / 64 * 64;
+  const size_t lds = (size_t)hcap * 4 + rest;
+  return {hbits, lds, hcap};
 }
+
 
 size_t exact_lds(uint32_t ef, uint32_t d) {
   return (size_t)TILE_ROWS * TILE_LD * 4 + 64 * 4 + 64 * 4 + 8 * 4 + (size_t)(ef + 1) * 8 + 16 +
@@ -349,6 +382,7 @@ struct CallGeometry {
   bool use_fast = false;
   FastGeom fg{};
   uint32_t slots = 0;      // resident waves of the launch
+  uint32_t vhint = 0;      // evaluations per query the visited table was sized for (0 = by ef alone)
   uint32_t plog_cap = 0;
   uint32_t tl_wcap = 0;
   size_t tl_lds = 0;
@@ -365,7 +399,10 @@ isl_status call_geometry(const isl_index* idx, uint64_t d, uint64_t k, uint64_t 
                      (unsigned long long)std::max(ef_in, k), kMaxExactEf);
   const uint32_t ef = g.ef;
   const int ncu = isl::device_cu_count(idx->device);
-  g.fg = fast_geometry(ef, (uint32_t)d);
+  // (searches over the recompute provider park their visited table in state blocks sized by ef alone; the
+  // two-level search sizes its own LDS: neither takes the hint)
+  g.vhint = (!tl && !idx->recompute) ? idx->evals_hint.load(std::memory_order_relaxed) : 0u;
+  g.fg = fast_geometry(ef, (uint32_t)d, 4, g.vhint);
   g.use_fast = ef <= 512 && ef >= 1 && idx->max_degree <= 128;
   // resident waves per CU: bounded by LDS (visited table + query) and by the kernel's VGPR
   // budget (<= 128 -> 4 per SIMD)
@@ -453,7 +490,7 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
   FastGeom fgq = fg;
   uint32_t slots_q = slots;
   if (qh) {
-    fgq = fast_geometry(ef, (uint32_t)d, 2);
+    fgq = fast_geometry(ef, (uint32_t)d, 2, cg.vhint);
     slots_q = (uint32_t)isl::device_cu_count(idx->device) *
               (uint32_t)std::max<size_t>(1, std::min<size_t>(waves_per_cu_cap(), (160 * 1024) / fgq.lds));
   }
@@ -524,6 +561,7 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
   p.plog = reinterpret_cast<uint2*>(ws.plog);
   p.plog_cap = plog_cap;
   p.hbits = fg.hbits;
+  p.hcap = fg.hcap;
   p.otab = ws.ovf_tab;
   p.obits = ws.ovf_bits;
   p.cand_d = idx->pool.cand_d;
@@ -649,8 +687,12 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
       p.qsel_h = ws.qsel_h;
       isl_launch::launch_classify((uint32_t)std::min<uint64_t>(nq_grid, 2048), st, &p);
       ISL_HIP(hipGetLastError());
+      p.hbits = fgq.hbits;
+      p.hcap = fgq.hcap;
       launch_fast(true, (uint32_t)std::min<uint64_t>(nq_grid, slots_q), fgq.lds);  // the bf16-valued queries
       ISL_HIP(hipGetLastError());
+      p.hbits = fg.hbits;
+      p.hcap = fg.hcap;
       p.qsel_mode = 1;  // the others
       launch_fast(false, grid, fg.lds);
       p.qsel_mode = 0;
@@ -753,6 +795,9 @@ isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws, uint32_
     ss.evals += ctr[i * 4 + 2];
     ss.pushes += ctr[i * 4 + 3];
   }
+  // what the next calls size their visited table by (fast_geometry): the evaluations per query of this one
+  if (use_fast && !idx->recompute && !misses && nq >= 16)
+    idx->evals_hint.store((uint32_t)std::min<uint64_t>(ss.evals / nq, 0xFFFFFFFFull), std::memory_order_relaxed);
   if (ws.d_tline) {
     std::vector<uint64_t> tl(nq * 2 + 2);
     tl[0] = 0x154C494E45ull;  // record header: magic, query count

@@ -59,7 +59,8 @@ struct SearchParams {
   uint64_t* tline;   // optional [nq][2]: start tick of every query (100 MHz); its duration | hops << 40; ISL_TIMELINE only
   uint2* plog;       // [nq][plog_cap] (distance bits, id) of every results.push, in order
   uint32_t plog_cap;
-  uint32_t hbits;    // LDS visited table: 1 << hbits entries
+  uint32_t hbits;    // LDS visited table: 1 << hbits entries where its size is part of a parked query's state block
+  uint32_t hcap;     // ... its entries (a multiple of 64; 1 << hbits unless sized by the index's evaluations per query)
   uint32_t* otab;    // overflow visited table in HBM, per slot
   uint32_t obits;
   // exact-kernel scratch
@@ -550,18 +551,18 @@ __device__ __forceinline__ uint32_t row_index(const SearchParams& p, uint32_t id
 // The set is an open-addressing table in LDS; once that is 7/8 full (`ovf`) new ids go to the
 // wave's overflow table in HBM.  (A function with value parameters, not a lambda: captures by
 // reference cost the headline kernel 37 VGPRs and a scratch frame.)
-__device__ __forceinline__ bool visited_insert(uint32_t* htab, uint32_t hbits, uint32_t hmask, bool ovf,
+__device__ __forceinline__ bool visited_insert(uint32_t* htab, uint32_t hcap, bool ovf,
                                                uint32_t* otab, uint32_t obits, uint32_t omask, uint32_t id,
                                                bool act) {
   bool fresh = false;
   if (act) {
-    uint32_t h = hslot(id, hbits);
+    uint32_t h = hslot_cap(id, hcap);
     if (!ovf) {
       for (;;) {
         uint32_t old = atomicCAS(&htab[h], EMPTY, id);
         if (old == EMPTY) { fresh = true; break; }
         if (old == id) break;
-        h = (h + 1) & hmask;
+        h = h + 1 == hcap ? 0u : h + 1;
       }
     } else {
       bool found = false;
@@ -569,7 +570,7 @@ __device__ __forceinline__ bool visited_insert(uint32_t* htab, uint32_t hbits, u
         uint32_t cur = htab[h];
         if (cur == id) { found = true; break; }
         if (cur == EMPTY) break;
-        h = (h + 1) & hmask;
+        h = h + 1 == hcap ? 0u : h + 1;
       }
       if (!found) {
         uint32_t g = hslot(id, obits);
@@ -618,8 +619,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void le
   const ROWT* const emb = reinterpret_cast<const ROWT*>(p.emb);
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
-  const uint32_t hcap = 1u << p.hbits;
-  const uint32_t hmask = hcap - 1;
+  const uint32_t hcap = p.hcap;
   const uint32_t hlimit = hcap - hcap / 8;  // load factor 0.875
   uint32_t* htab = reinterpret_cast<uint32_t*>(smem);
   // merge buffer of batch_insert; its head doubles as the 64 words of the id compaction
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void le
       float ed = direct_distances<METRIC, ROWT, QH>(emb, p.stride, p.d, erow, 1, qs, q_norm, e_aux);
       ed = rl_f(ed, 0);
       cV = p.q_entry ? p.q_evals[qi] : 1;
-      if (lane == 0) htab[hslot(entry, p.hbits)] = entry;
+      if (lane == 0) htab[hslot_cap(entry, hcap)] = entry;
       hcount = 1;
       if (odd_distance(ed) && status == QS_OK) { status = QS_REDO; payload = 5; }
       rs.insert(ordkey(ed), entry, ef);
@@ -805,14 +805,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void le
       ISL_MARK(tp0)  // selection + adjacency fetch
       // visited.insert(n), leann.rs:933-937 (rows hold no duplicate ids on the device)
       if (!ovf && hcount + deg > hlimit) ovf = true;
-      const bool is_new = visited_insert(htab, p.hbits, hmask, ovf, otab, p.obits, omask, nid, active);
+      const bool is_new = visited_insert(htab, hcap, ovf, otab, p.obits, omask, nid, active);
       uint64_t nm = ballot(is_new);
       nu = (uint32_t)__popcll(nm);
       bool is_new1 = false;
       uint64_t nm1 = 0;
       if constexpr (WIDE) {
         if (deg > 64) {
-          is_new1 = visited_insert(htab, p.hbits, hmask, ovf, otab, p.obits, omask, nid1, (uint32_t)lane + 64u < deg);
+          is_new1 = visited_insert(htab, hcap, ovf, otab, p.obits, omask, nid1, (uint32_t)lane + 64u < deg);
           nm1 = ballot(is_new1);
           nu += (uint32_t)__popcll(nm1);
         }
@@ -1508,8 +1508,7 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
   const ROWT* const emb = reinterpret_cast<const ROWT*>(p.emb);
   extern __shared__ __align__(16) unsigned char smem[];
   const uint32_t lane = threadIdx.x;
-  const uint32_t hcap = 1u << p.hbits;
-  const uint32_t hmask = hcap - 1;
+  const uint32_t hcap = p.hcap;
   const uint32_t hlimit = hcap - hcap / 8;
   const uint32_t ef = p.ef;
   const uint32_t wcap = p.tl_wcap;
@@ -1604,7 +1603,7 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
       ed = rl_f(ed, 0);
       cV = 1;
       if (lane == 0) {
-        htab[hslot(entry, p.hbits)] = entry;
+        htab[hslot_cap(entry, hcap)] = entry;
         res[0] = ((uint64_t)ordkey(ed) << 32) | ((uint64_t)entry << 1);
       }
       hcount = 1;
@@ -1642,7 +1641,7 @@ __global__ __launch_bounds__(64) void leann_search_two_level(SearchParams p) {
         const uint32_t nid = active ? p.adj[o0 + base + lane] : EMPTY;
         const uint32_t batch = deg - base < 64 ? deg - base : 64;
         if (!ovf && hcount + batch > hlimit) ovf = true;
-        const bool is_new = visited_insert(htab, p.hbits, hmask, ovf, otab, p.obits, omask, nid, active);
+        const bool is_new = visited_insert(htab, hcap, ovf, otab, p.obits, omask, nid, active);
         const uint64_t nm = ballot(is_new);
         const uint32_t nu = (uint32_t)__popcll(nm);
         if (!ovf) hcount += nu;

@@ -284,6 +284,26 @@ def test_mid_size_d768_matches_oracle(orc):
             assert st[f] == tot[f]
 
 
+def test_visited_table_grows_with_the_evaluations_the_index_sees(orc):
+    """The size of a query's visited table in LDS follows the evaluations per query of the index's previous call
+    (fast_geometry, round 4): the first call over this graph -- ~60 fresh neighbours per expansion, several
+    thousand evaluations per query -- runs with the table ef alone gives (most queries spill into the HBM overflow
+    table), the next ones with the next size up.  Same ids, distance bits and counters every time."""
+    n, d, deg = 9000, 24, 60
+    v = uniform_vectors(n, d, 17)
+    off, nb = random_csr(n, deg, 23)
+    csr = orc.Csr(off, nb, entry_point=7)
+    idx = make_index(csr, v)
+    q = uniform_vectors(48, d, 29)
+    evals = []
+    for rep in range(3):
+        st, tot = assert_same_search(orc, idx, csr, v, q, 10, 128)
+        for f in tot:
+            assert st[f] == tot[f], (f, rep)
+        evals.append(st["evals"] / q.shape[0])
+    assert evals[0] > 1792 * 1.2  # (the case does exercise a table past its 7/8 limit)
+
+
 def test_device_born_csr_and_device_buffers(orc):
     torch = pytest.importorskip("torch")
     n, d = 2000, 64

@@ -13,3 +13,10 @@ for l in open("gpurun_out/r04_recompute_1m_prefetch_ab.jsonl"):
         d = json.loads(l)
         print({k: d.get(k) for k in ("run", "value", "seconds", "rounds", "encoded_nodes", "recall_at_10", "equals_in_memory_provider")}, d.get("roofline", {}).get("frac"))
 PY
+echo "== visited table size on dataset M (V ~ 3100 per query), 1M rows, kNN graph"
+for hb in 11 12 13; do
+  ISL_HBITS=$hb timeout -k 10 300 python bench.py --dataset M --graph knn --nodes 1000000 --steps 20 --warmup 5 --no-traffic --no-cpu-baseline --no-host-path > gpurun_out/r04_bench_M_knn_1m_hbits$hb.json 2> gpurun_out/r04_bench_M_knn_1m_hbits$hb.err || { tail -20 gpurun_out/r04_bench_M_knn_1m_hbits$hb.err; exit 1; }
+  python3 -c "
+import json; d=json.loads(open('gpurun_out/r04_bench_M_knn_1m_hbits$hb.json').read().strip().splitlines()[-1])
+print('hbits $hb', d['value'], d['recall_at_10'], d['roofline']['frac'], d['config']['per_query'])"
+done
