@@ -207,6 +207,27 @@ def measure_traffic(args):
             "traffic_over_algorithmic": round(traffic / alg, 4) if alg else None}
 
 
+def measure_neutral(args):
+    """`neutral_workload` of the default line: this script once more, as a child, on dataset M / --graph knn /
+    1M rows with the same query batch, k, ef, steps and warm-up."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--dataset", "M", "--graph", "knn", "--nodes", "1000000", "--dim", str(args.dim), "--nq", str(args.nq),
+           "--k", str(args.k), "--ef", str(args.ef), "--no-traffic", "--no-cpu-baseline", "--no-host-path", "--no-neutral-side"]
+    t0 = time.time()
+    pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    line = [l for l in pr.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if pr.returncode != 0 or not line:
+        raise RuntimeError(f"child rc={pr.returncode}: {pr.stderr.decode(errors='replace')[-200:]}")
+    r = json.loads(line[-1])
+    return {"value": r["value"], "unit": r["unit"], "recall_at_10": r["recall_at_10"], "ms_per_step": r["ms_per_step"],
+            "roofline_frac": r["roofline"]["frac"], "per_query": r["config"]["per_query"],
+            "workload": r["config"]["workload"], "graph_build_s": r["config"]["graph_build_s"],
+            "child_run_s": round(time.time() - t0, 1),
+            "command": "python bench.py --dataset M --graph knn --nodes 1000000 (same nq, k, ef, steps, warm-up)"}
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- as children of
     torch.distributed.run, one per GPU -- BEFORE this process has made any GPU call (it never does),
@@ -294,6 +315,10 @@ def main():
                     help="when recall@10 at --ef misses 0.95: the larger ef values tried (one after the other, "
                          "until one reaches it); empty = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-neutral-side", action="store_true",
+                    help="skip the side measurement the default (headline) configuration carries in `neutral_workload`: "
+                         "1M rows without a cluster tree (dataset M) on the exact-kNN graph the library's own brute force "
+                         "builds, same nq / k / ef / steps, as a child process")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer pipelined measurement")
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not re-run this configuration under rocprofv3 --pmc FETCH_SIZE for roofline.traffic")
@@ -756,6 +781,16 @@ def main():
         except Exception as e:  # the baseline must never take the measured number down with it
             result["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0,
                                       "kind": "port", "sample": f"failed: {e!r}"}
+    if (rank == 0 and world == 1 and not args.no_neutral_side and not args.traffic_child and args.dataset == "G"
+            and args.graph == "harness" and not args.rehearse_shard and args.row_dtype == "f32"):
+        # The headline's rows and graph come from one harness (a tree of clusters and a graph built from that
+        # tree).  Beside it, in the same line: rows nobody designed a graph for and the graph anybody would build
+        # first -- exact nearest-neighbour lists by the library's brute force -- at 1M rows (the 10M build takes
+        # five minutes: profiles/r04_bench_M_knn_10m.json).  A child process; this one has long finished timing.
+        try:
+            result["neutral_workload"] = measure_neutral(args)
+        except Exception as e:
+            result["neutral_workload"] = {"value": None, "note": f"not measured: {e!r}"[:300]}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
