@@ -167,7 +167,7 @@ constexpr int FBK = 32;  // floats per slab row
 
 // EXP (tools/microbench/gemm_f32_exp.hip only): bit 0 = per-element epilogue stores, bit 1 = no staggered start.
 template <int ACT, bool RES, int WM, int WN, int MF, int NF, int EXP = 0>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_tn_f32_dma(const float* __restrict__ A,
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((flatten)) void gemm_tn_f32_dma(const float* __restrict__ A,
                                                                 const float* __restrict__ W,
                                                                 const float* __restrict__ bias,
                                                                 const float* __restrict__ R,
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_f32_dma(const float* __r
         bv4 = *reinterpret_cast<const float4*>(bias + nvc);
         asm volatile("" : "+v"(bv4.x), "+v"(bv4.y), "+v"(bv4.z), "+v"(bv4.w));
       }
-#pragma unroll
+#pragma clang loop unroll(full)
       for (int i = 0; i < MF; ++i) {
 #pragma unroll
         for (int j = 0; j < NF; ++j)
@@ -364,33 +364,45 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_f32_dma(const float* __r
           for (int r = 0; r < 16; ++r) sc[(8 * (r / 4) + 4 * kh + (r % 4)) * WCOLS + 32 * j + c32] = acc[i][j][r];
         // (LDS operations of one wave complete in order: the reads below see the writes above)
         if (vec_ok) {
-          float4 rv4[NQ];
-          float rn[NQ];
-#pragma unroll
-          for (uint32_t q = 0; q < NQ; ++q) {
-            const uint64_t m = m0 + wm + 32 * i + q * RPQ + row0, mc = m < M ? m : (uint64_t)M - 1;
-            rv4[q] = float4{0.0f, 0.0f, 0.0f, 0.0f};
-            rn[q] = 0.0f;
-            if (RES) rv4[q] = *reinterpret_cast<const float4*>(R + mc * N + nvc);
-            if (ROWNORM) rn[q] = R[mc];
-          }
-#pragma unroll
-          for (uint32_t q = 0; q < NQ; ++q) {
-            if (RES) asm volatile("" : "+v"(rv4[q].x), "+v"(rv4[q].y), "+v"(rv4[q].z), "+v"(rv4[q].w));
-            if (ROWNORM) asm volatile("" : "+v"(rn[q]));
-          }
-#pragma unroll
-          for (uint32_t q = 0; q < NQ; ++q) {
+          auto store_row = [&](uint32_t q, const float4& rv, float rnq) {
             const uint32_t row = q * RPQ + row0;
             const float4 v = *reinterpret_cast<const float4*>(sc + row * WCOLS + 4 * c4);
             const uint64_t m = m0 + wm + 32 * i + row;
-            if (m >= M || nv >= N) continue;
+            if (m >= M || nv >= N) return;
             float4 o;
-            o.x = finish(v.x, bv4.x, RES ? rv4[q].x : rn[q]);
-            o.y = finish(v.y, bv4.y, RES ? rv4[q].y : rn[q]);
-            o.z = finish(v.z, bv4.z, RES ? rv4[q].z : rn[q]);
-            o.w = finish(v.w, bv4.w, RES ? rv4[q].w : rn[q]);
+            o.x = finish(v.x, bv4.x, RES ? rv.x : rnq);
+            o.y = finish(v.y, bv4.y, RES ? rv.y : rnq);
+            o.z = finish(v.z, bv4.z, RES ? rv.z : rnq);
+            o.w = finish(v.w, bv4.w, RES ? rv.w : rnq);
             *reinterpret_cast<float4*>(C + m * ldc + nv) = o;
+          };
+          if constexpr (RES || ROWNORM) {
+            // eight rows' loads in one go, pinned in front of their eight stores (a 128 x 128 wave tile has 16 per block)
+            constexpr uint32_t QC = NQ < 8 ? NQ : 8;
+#pragma unroll
+            for (uint32_t q0 = 0; q0 < NQ; q0 += QC) {
+              float4 rv4[QC];
+              float rn[QC];
+#pragma unroll
+              for (uint32_t q = 0; q < QC; ++q) {
+                const uint64_t m = m0 + wm + 32 * i + (q0 + q) * RPQ + row0, mc = m < M ? m : (uint64_t)M - 1;
+                rv4[q] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+                rn[q] = 0.0f;
+                if (RES) rv4[q] = *reinterpret_cast<const float4*>(R + mc * N + nvc);
+                if (ROWNORM) rn[q] = R[mc];
+              }
+#pragma unroll
+              for (uint32_t q = 0; q < QC; ++q) {
+                if (RES) asm volatile("" : "+v"(rv4[q].x), "+v"(rv4[q].y), "+v"(rv4[q].z), "+v"(rv4[q].w));
+                if (ROWNORM) asm volatile("" : "+v"(rn[q]));
+              }
+#pragma unroll
+              for (uint32_t q = 0; q < QC; ++q) store_row(q0 + q, rv4[q], rn[q]);
+            }
+          } else {
+            const float4 zero = float4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (uint32_t q = 0; q < NQ; ++q) store_row(q, zero, 0.0f);
           }
         } else {
 #pragma unroll
@@ -433,14 +445,35 @@ void launch_gemm(const float* A, const float* W, const float* bias, const float*
     if (big >= 384) {
       // persistent: one workgroup per CU (128 KiB of LDS each) walks its tiles, the next tile's first
       // slab in flight under the current tile's last
-      auto kern = gemm_tn_f32_dma<ACT, RES, 2, 4, 4, 2>;
       constexpr size_t lds = 2 * (256 + 256) * FBK * 4;
+      const uint32_t grid = (uint32_t)(big < cus ? big : cus);
+      // Round 4: the plain and the residual epilogue run the 256 x 256 tile on FOUR waves, 128 x 128 per wave (16
+      // accumulator blocks = 256 accumulator registers, one wave per SIMD): 8 fragment reads per 64 MFMAs instead of 6
+      // per 32, same k order, same bits.  Measured in one process (tools/microbench/gemm_f32_w4.hip,
+      // profiles/r04_gemm_f32_w4.log; M = 524288): bias only 135.7 -> 139.5 TFLOP/s at K = 768 and 137.8 -> 143.6 at
+      // K = 3072 (hipBLASLt: 141.5), bias + residual 125.4 -> 128.8 / 132.1 -> 139.7.  The GELU epilogue stays on eight
+      // waves (126.9 against 118.8: with one wave per SIMD nothing runs beside a wave's 256 inlined erff), and so do
+      // the distance epilogues.  ISL_GEMM_F32_W4=0: eight waves everywhere (A/B switch).
+      static const bool w4 = [] { const char* e = getenv("ISL_GEMM_F32_W4"); return !e || atoi(e) != 0; }();
+      if constexpr (ACT == 0) {
+        if (w4) {
+          auto kern = gemm_tn_f32_dma<ACT, RES, 2, 2, 4, 4>;
+          static const bool once4 = [&] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            return true;
+          }();
+          (void)once4;
+          hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A, W, bias, R, C, (uint32_t)M, (uint32_t)N,
+                             (uint32_t)K, (uint32_t)((N + 255) / 256), N, (uint32_t)big);
+          return;
+        }
+      }
+      auto kern = gemm_tn_f32_dma<ACT, RES, 2, 4, 4, 2>;
       static const bool once = [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         return true;
       }();
       (void)once;
-      const uint32_t grid = (uint32_t)(big < cus ? big : cus);
       hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, W, bias, R, C, (uint32_t)M, (uint32_t)N,
                          (uint32_t)K, (uint32_t)((N + 255) / 256), N, (uint32_t)big);
     } else {

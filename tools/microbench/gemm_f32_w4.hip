@@ -76,6 +76,9 @@ int main(int argc, char** argv) {
            M, N, K, round, t8, fl / t8 / 1e9, t4, fl / t4 / 1e9, fl / r8 / 1e9, fl / r4 / 1e9, fl / g8 / 1e9, fl / g4 / 1e9);
     fflush(stdout);
   }
+  (void)run<0, false, 2, 4, 4, 2>(A, W, bias, nullptr, C, M, N, K, 1);
+  (void)run<0, false, 2, 2, 4, 4>(A, W, bias, nullptr, C2, M, N, K, 1);
+  printf("bias-only outputs, differing elements of %llu: %llu\n", (unsigned long long)M * N, differing(C, C2, (uint64_t)M * N));
   (void)run<0, true, 2, 4, 4, 2>(A, W, bias, R, C, M, N, K, 1);
   (void)run<0, true, 2, 2, 4, 4>(A, W, bias, R, C2, M, N, K, 1);
   printf("bias + residual outputs, differing elements of %llu: %llu\n", (unsigned long long)M * N, differing(C, C2, (uint64_t)M * N));
