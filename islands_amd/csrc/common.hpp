@@ -91,6 +91,7 @@ struct SearchWorkspace {
   bool publish_results = false; // host-buffer call: the publish kernel also brings the answers home
   uint64_t token = 0;
   uint64_t nq_inflight = 0, k_inflight = 0;
+  uint32_t ef_inflight = 0;  // the effective ef (max(ef, k)) of the call in flight
   bool fast_inflight = false;
   hipStream_t st_inflight = nullptr;
   // host-pointer call in flight: where the answers go at wait time
@@ -201,9 +202,10 @@ struct isl_index {
   uint32_t* d_adj = nullptr;  // [nnz] (duplicates within a row removed, first occurrence kept)
   uint64_t nnz = 0;
   uint32_t max_degree = 0;
-  // distance evaluations per query of the most recent in-memory search call (0 = none yet): the size of the
-  // visited table follows it (search.hip, fast_geometry)
-  mutable std::atomic<uint32_t> evals_hint{0};
+  // distance evaluations per query of the most recent in-memory search call and the ef it ran with, packed
+  // (ef << 32 | evaluations; 0 = none yet): the size of the visited table of later calls WITH THAT ef follows it
+  // (search.hip, fast_geometry)
+  mutable std::atomic<uint64_t> evals_hint{0};
   // in-memory provider (leann.rs:104-159): nvec rows, `stride` floats apart
   float* d_emb = nullptr;
   uint16_t* d_emb16 = nullptr;  // bf16 rows (ISL_DTYPE_BF16) instead of d_emb

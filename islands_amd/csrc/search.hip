@@ -401,7 +401,11 @@ isl_status call_geometry(const isl_index* idx, uint64_t d, uint64_t k, uint64_t 
   const int ncu = isl::device_cu_count(idx->device);
   // (searches over the recompute provider park their visited table in state blocks sized by ef alone; the
   // two-level search sizes its own LDS: neither takes the hint)
-  g.vhint = (!tl && !idx->recompute) ? idx->evals_hint.load(std::memory_order_relaxed) : 0u;
+  g.vhint = 0;
+  if (!tl && !idx->recompute) {  // (the evaluations of a call with another ef say nothing about this one)
+    const uint64_t h = idx->evals_hint.load(std::memory_order_relaxed);
+    if ((uint32_t)(h >> 32) == ef) g.vhint = (uint32_t)h;
+  }
   g.fg = fast_geometry(ef, (uint32_t)d, 4, g.vhint);
   g.use_fast = ef <= 512 && ef >= 1 && idx->max_degree <= 128;
   // resident waves per CU: bounded by LDS (visited table + query) and by the kernel's VGPR
@@ -725,6 +729,7 @@ isl_status search_enqueue_impl(const isl_index* idx, isl::SearchWorkspace& ws, c
   ws.enqueued = true;
   ws.nq_inflight = nq;
   ws.k_inflight = k;
+  ws.ef_inflight = ef;
   ws.fast_inflight = use_fast;
   return ISL_OK;
 }
@@ -797,7 +802,8 @@ isl_status search_finish(const isl_index* idx, isl::SearchWorkspace& ws, uint32_
   }
   // what the next calls size their visited table by (fast_geometry): the evaluations per query of this one
   if (use_fast && !idx->recompute && !misses && nq >= 16)
-    idx->evals_hint.store((uint32_t)std::min<uint64_t>(ss.evals / nq, 0xFFFFFFFFull), std::memory_order_relaxed);
+    idx->evals_hint.store(((uint64_t)ws.ef_inflight << 32) | std::min<uint64_t>(ss.evals / nq, 0xFFFFFFFFull),
+                          std::memory_order_relaxed);
   if (ws.d_tline) {
     std::vector<uint64_t> tl(nq * 2 + 2);
     tl[0] = 0x154C494E45ull;  // record header: magic, query count
