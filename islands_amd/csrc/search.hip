@@ -251,8 +251,14 @@ isl_status prepare_workspace(const isl_index* idx, isl::SearchWorkspace& ws, uin
     if (ws.ovf_tab) (void)hipFree(ws.ovf_tab);
     ws.ovf_tab = nullptr;
     ws.slots = 0;
-    ws.ovf_bits = kOvfBits;
-    uint64_t n = (uint64_t)slots << kOvfBits;
+    // (ISL_OVF_BITS: the overflow table's size for measurements; a query that fills 3/4 of it goes to the heap-exact kernel)
+    static const uint32_t ovf_bits_cfg = [] {
+      const char* e = getenv("ISL_OVF_BITS");
+      const int v = e ? atoi(e) : (int)kOvfBits;
+      return (uint32_t)std::min(15, std::max(10, v));
+    }();
+    ws.ovf_bits = ovf_bits_cfg;
+    uint64_t n = (uint64_t)slots << ovf_bits_cfg;
     ISL_TRY(lane_malloc(ws, ws.ovf_tab, n * 4));
     hipLaunchKernelGGL(fill_u32_kernel, dim3(2048), dim3(256), 0, ws.stream, ws.ovf_tab, n, EMPTY);
     ISL_HIP(hipGetLastError());
