@@ -251,7 +251,14 @@ isl_status isl_search_batch_device(const isl_index* idx, const float* d_queries,
  * returns for *token (token 0 = the call was answered immediately).  An index with the recompute
  * provider is accepted too (this form and isl_search_batch_async): the provider works through the
  * batch in rounds -- search, encode what was missed, resume -- on a host thread of the library's,
- * one such call at a time per index; isl_search_stream_wait then waits on the host. */
+ * one set of rounds at a time per index; isl_search_stream_wait then waits on the host.  Calls of
+ * this form (and of isl_search_two_level_batch_device_async) that are waiting for their turn are
+ * answered TOGETHER by the call that gets it, when they agree in d, k, ef and search kind: one set of
+ * rounds over the union of their queries, so a node several of them need is encoded once and the
+ * encoder gets fuller passes (Searcher::search_batch, search.rs:179-181, hands batches over one by one;
+ * how they are batched on the device is the library's business).  Each call's answers, status and
+ * counters are its own (recompute_rounds / encoded_nodes of its statistics are the shared rounds'); if
+ * the union fails, every member is run by itself and gets its own error. */
 isl_status isl_search_batch_device_async(const isl_index* idx, const float* d_queries, uint64_t nq,
                                          uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_out_ids,
                                          float* d_out_dist, uint32_t* d_out_count, void* stream,

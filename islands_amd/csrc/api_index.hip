@@ -82,7 +82,8 @@ int device_cu_count(int32_t device) {
 void free_workspace(SearchWorkspace& ws) {
   void* ptrs[] = {ws.ovf_tab, ws.status,  ws.payload,   ws.ctr,        ws.ticket,     ws.redo, ws.replay, ws.qsel, ws.qsel_h, ws.plog,
                   ws.q_stage, ws.ids_stage, ws.dist_stage, ws.count_stage, ws.d_prof, ws.d_tline, ws.q_entry, ws.miss, ws.uniq,
-                  ws.uniq_count, ws.tl_tables, ws.qstate, ws.qflag, ws.qlist, ws.uslots, ws.xslot};
+                  ws.uniq_count, ws.tl_tables, ws.qstate, ws.qflag, ws.qlist, ws.uslots, ws.xslot, ws.co_q, ws.co_ids, ws.co_dist,
+                  ws.co_cnt};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   void* pinned[] = {ws.h_status, ws.h_ctr, ws.h_head, ws.h_q, ws.h_ids, ws.h_dist, ws.h_count, ws.h_qlist, ws.h_xlist};

@@ -106,6 +106,15 @@ struct SearchWorkspace {
   uint64_t* d_tline = nullptr;   // ISL_TIMELINE: [nq][2] start / end ticks of every query of the call in flight
   uint32_t* q_entry = nullptr;   // HnswGraph: [2][nq] layer-0 entry and descent evaluations per query
   uint64_t q_entry_cap = 0;
+  // recompute provider: the union of the calls this lane answers as one (search.hip, recompute_coalesced)
+  float* co_q = nullptr;
+  uint64_t co_q_cap = 0;
+  uint64_t* co_ids = nullptr;
+  uint64_t co_ids_cap = 0;
+  float* co_dist = nullptr;
+  uint64_t co_dist_cap = 0;
+  uint32_t* co_cnt = nullptr;
+  uint64_t co_cnt_cap = 0;
   // recompute provider: node ids whose rows a search round found absent, and their unique set
   uint32_t* miss = nullptr;
   uint32_t* uniq = nullptr;
@@ -252,6 +261,14 @@ struct isl_index {
 
   mutable std::mutex mu;  // lane claims, the exact pool, index mutation -- never held across a search
   mutable std::mutex recompute_mu;  // searches over the recompute provider share its row table
+  // asynchronous calls over the recompute provider that wait for their turn: the one that gets it answers every
+  // compatible call waiting at that moment together with its own (search.hip, recompute_coalesced)
+  struct RecJoin {
+    std::mutex mu;        // guards `waiting`
+    std::mutex leader;    // held by the call that is running the rounds
+    std::vector<void*> waiting;
+  };
+  mutable RecJoin rec_join;
   mutable isl::SearchWorkspace ws[isl::kSearchLanes];
   mutable isl::ExactPool pool;
   mutable uint64_t next_token = 1;

@@ -274,6 +274,103 @@ def test_recompute_encoder_passes_split_in_two_answer_the_same(orc, monkeypatch)
     assert len(set(encoded.values())) == 1
 
 
+def test_concurrent_recompute_calls_are_answered_together(orc):
+    """Asynchronous device-buffer calls over the recompute provider queue for their turn; the call that gets it
+    answers every compatible call waiting at that moment together with its own, in one set of rounds over the
+    union of their queries (recompute_coalesced): each call's ids, distance bits, counts and counters are those
+    of the in-memory provider, calls with another ef are not merged, and the calls that were merged report the
+    same rounds."""
+    import torch
+    cfg, enc, tok, lens, emb = _recompute_case(orc, n=1600, seed=31, min_len=7)
+    n, d = emb.shape
+    from _data import random_csr
+    off, nb = random_csr(n, 24, 13)
+    csr = orc.Csr(off, nb, entry_point=2)
+    g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels, entry_point=2,
+                    num_nodes=n, degree_counts=csr.degree_counts)
+    mem_idx = ia.LeannIndex.from_csr(g, None, dimension=d).upload(0)
+    mem_idx.set_embeddings(emb)
+    rec_idx = ia.LeannIndex.from_csr(g, None, dimension=d).upload(0)
+    rec_idx.set_recompute_provider(enc, tok, lens)
+    rng = np.random.default_rng(3)
+    calls = []
+    for i, (nq, ef) in enumerate([(40, 64), (33, 64), (57, 64), (20, 32), (41, 64), (9, 64)]):
+        q = (emb[rng.integers(0, n, nq)] + rng.standard_normal((nq, d)).astype(np.float32) * np.float32(0.03)).astype(np.float32)
+        calls.append((q, 10, ef))
+    dev = torch.device("cuda:0")
+    bufs, toks = [], []
+    for (q, k, ef) in calls:
+        dq = torch.from_numpy(q).to(dev)
+        o = (torch.zeros((q.shape[0], k), dtype=torch.int64, device=dev), torch.zeros((q.shape[0], k), dtype=torch.float32, device=dev),
+             torch.zeros(q.shape[0], dtype=torch.int32, device=dev))
+        bufs.append((dq, o))
+    torch.cuda.synchronize()
+    for (q, k, ef), (dq, o) in zip(calls, bufs):
+        toks.append(rec_idx.search_batch_device_async(dq.data_ptr(), q.shape[0], d, k, ef, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr()))
+    stats = [rec_idx.wait_stats(t) for t in toks]
+    torch.cuda.synchronize()
+    for (q, k, ef), (dq, o), st in zip(calls, bufs, stats):
+        want = mem_idx.search_batch(q, k, ef)
+        ws = mem_idx.last_stats()
+        assert o[2].cpu().numpy().astype(np.uint32).tolist() == want[2].tolist()
+        assert o[0].cpu().numpy().astype(np.uint64).tolist() == want[0].tolist()
+        assert o[1].cpu().numpy().view(np.uint32).tolist() == want[1].view(np.uint32).tolist()
+        for f in ("expansions", "edges", "evals", "pushes"):
+            assert st[f] == ws[f], (f, q.shape[0], ef)
+        assert st["queries"] == q.shape[0]
+    # the first call had the turn alone or with whatever had arrived; the ef = 64 calls behind it were answered together
+    merged_rounds = {st["recompute_rounds"] for (q, k, ef), st in zip(calls[1:], stats[1:]) if ef == 64}
+    assert len(merged_rounds) <= 2
+
+
+def test_concurrent_recompute_calls_that_fail_get_their_own_errors(orc):
+    """A graph that names a node the provider has no tokens for: every search that reaches it fails with
+    NodeNotFound (leann.rs:145-150).  Calls answered together must not share that fate blindly -- when the union
+    fails, every member is run by itself: each call's outcome (answers or error) is what the same call gives alone."""
+    import torch
+    cfg, enc, tok, lens, emb = _recompute_case(orc, n=400, seed=5, min_len=7)
+    n, d = emb.shape
+    from _data import random_csr
+    off, nb = random_csr(n, 8, 21)
+    nb = nb.copy()
+    nb[off[37]] = n + 5  # node 37's first neighbour does not exist
+    csr = orc.Csr(off, nb, entry_point=1)
+    g = ia.CsrGraph(node_offsets=csr.node_offsets, neighbors=csr.neighbors, levels=csr.levels, entry_point=1,
+                    num_nodes=n, degree_counts=csr.degree_counts)
+    rec_idx = ia.LeannIndex.from_csr(g, None, dimension=d).upload(0)
+    rec_idx.set_recompute_provider(enc, tok, lens)
+    rng = np.random.default_rng(8)
+    qs = [(emb[rng.integers(0, n, m)] + np.float32(0.01)).astype(np.float32) for m in (12, 7, 30, 5)]
+    alone = []
+    for q in qs:  # what each call gives by itself
+        try:
+            alone.append(("ok", rec_idx.search_batch(q, 5, 6)))
+        except ia.CoreError as e:
+            alone.append((e.kind, e.node))
+    assert any(a[0] == "NodeNotFound" for a in alone)
+    dev = torch.device("cuda:0")
+    bufs = []
+    for q in qs:
+        bufs.append((torch.from_numpy(q).to(dev), torch.zeros((q.shape[0], 5), dtype=torch.int64, device=dev),
+                     torch.zeros((q.shape[0], 5), dtype=torch.float32, device=dev), torch.zeros(q.shape[0], dtype=torch.int32, device=dev)))
+    torch.cuda.synchronize()
+    toks = [rec_idx.search_batch_device_async(b[0].data_ptr(), q.shape[0], d, 5, 6, b[1].data_ptr(), b[2].data_ptr(), b[3].data_ptr())
+            for q, b in zip(qs, bufs)]
+    for q, b, t, a in zip(qs, bufs, toks, alone):
+        try:
+            rec_idx.wait(t)
+            got = ("ok",)
+        except ia.CoreError as e:
+            got = (e.kind, e.node)
+        if a[0] == "ok":
+            assert got == ("ok",)
+            torch.cuda.synchronize()
+            assert b[1].cpu().numpy().astype(np.uint64).tolist() == a[1][0].tolist()
+            assert b[2].cpu().numpy().view(np.uint32).tolist() == a[1][1].view(np.uint32).tolist()
+        else:
+            assert got == a
+
+
 def test_recompute_provider_keeps_rows_when_asked(orc):
     cfg, enc, tok, lens, emb = _recompute_case(orc, n=400, seed=9)
     levels = np.zeros(400, np.uint64)
