@@ -252,7 +252,7 @@ isl_status isl_search_batch_device(const isl_index* idx, const float* d_queries,
  * provider is accepted too (this form and isl_search_batch_async): the provider works through the
  * batch in rounds -- search, encode what was missed, resume -- on a host thread of the library's,
  * one set of rounds at a time per index; isl_search_stream_wait then waits on the host.  Calls of
- * this form (and of isl_search_two_level_batch_device_async) that are waiting for their turn are
+ * this form (and of isl_search_batch_async and isl_search_two_level_batch_device_async) that are waiting for their turn are
  * answered TOGETHER by the call that gets it, when they agree in d, k, ef and search kind: one set of
  * rounds over the union of their queries, so a node several of them need is encoded once and the
  * encoder gets fuller passes (Searcher::search_batch, search.rs:179-181, hands batches over one by one;

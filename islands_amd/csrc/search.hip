@@ -1362,7 +1362,11 @@ isl_status recompute_coalesced(const isl_index* idx, isl::SearchWorkspace& ws, c
     o += c->nq;
   }
   if (!copied) { (void)hipStreamSynchronize(st); (void)hipGetLastError(); return fall_back(); }
+  // (a host-buffer call's lane publishes its answers into pinned mirrors sized for THAT call: not for the union)
+  const bool publishes = ws.publish_results;
+  ws.publish_results = false;
   const isl_status rc = search_sync(idx, ws, ws.co_q, total, d, k, ef, ws.co_ids, ws.co_dist, ws.co_cnt, nullptr, StreamMode::OWN, tl);
+  ws.publish_results = publishes;
   if (rc != ISL_OK) return fall_back();
   const isl_search_stats all = ws.stats;
   o = 0;
@@ -1373,6 +1377,15 @@ isl_status recompute_coalesced(const isl_index* idx, isl::SearchWorkspace& ws, c
       scattered = scattered && hipMemcpyAsync(c->dist, ws.co_dist + o * k, c->nq * k * 4, hipMemcpyDeviceToDevice, st) == hipSuccess;
     }
     scattered = scattered && hipMemcpyAsync(c->cnt, ws.co_cnt + o, c->nq * 4, hipMemcpyDeviceToDevice, st) == hipSuccess;
+    if (c->ws->publish_results) {  // a host-buffer call (isl_search_batch_async): its wait copies out of the lane's pinned mirrors
+      if (k) {
+        scattered = scattered && hipMemcpyAsync(c->ws->h_ids, ws.co_ids + o * k, c->nq * k * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
+        scattered = scattered && hipMemcpyAsync(c->ws->h_dist, ws.co_dist + o * k, c->nq * k * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+      }
+      scattered = scattered && hipMemcpyAsync(c->ws->h_count, ws.co_cnt + o, c->nq * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+      c->ws->nq_inflight = c->nq;
+      c->ws->k_inflight = c->k;
+    }
     o += c->nq;
   }
   scattered = scattered && hipStreamSynchronize(st) == hipSuccess;
@@ -1793,9 +1806,9 @@ isl_status isl_search_batch_async(const isl_index* idx, const float* queries, ui
   LaneGuard guard{idx, ws};
   ISL_TRY(host_stage_in(idx, *ws, queries, nq, d, k));
   if (idx->recompute) {
+    ISL_HIP(hipEventRecord(ws->ev_in, ws->stream));  // the staged queries are there (a call that answers this one with its own waits for it)
     ISL_TRY(start_worker(idx, ws, [=]() {
-      return search_sync(idx, *ws, ws->q_stage, nq, d, k, ef, ws->ids_stage, ws->dist_stage, ws->count_stage, nullptr,
-                         StreamMode::OWN);
+      return recompute_coalesced(idx, *ws, ws->q_stage, nq, d, k, ef, ws->ids_stage, ws->dist_stage, ws->count_stage, nullptr);
     }));
   } else
   ISL_TRY(search_enqueue(idx, *ws, ws->q_stage, nq, d, k, ef, ws->ids_stage, ws->dist_stage, ws->count_stage,

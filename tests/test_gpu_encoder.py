@@ -321,6 +321,18 @@ def test_concurrent_recompute_calls_are_answered_together(orc):
     # the first call had the turn alone or with whatever had arrived; the ef = 64 calls behind it were answered together
     merged_rounds = {st["recompute_rounds"] for (q, k, ef), st in zip(calls[1:], stats[1:]) if ef == 64}
     assert len(merged_rounds) <= 2
+    # the host-buffer form (isl_search_batch_async: pageable arrays in and out) goes through the same turn
+    outs = [(np.zeros((q.shape[0], k), np.uint64), np.zeros((q.shape[0], k), np.float32), np.zeros(q.shape[0], np.uint32))
+            for (q, k, ef) in calls]
+    toks = [rec_idx.search_batch_async(q, k, ef, out=o) for (q, k, ef), o in zip(calls, outs)]
+    hstats = [rec_idx.wait_stats(t) for t in toks]
+    for (q, k, ef), o, st in zip(calls, outs, hstats):
+        want = mem_idx.search_batch(q, k, ef)
+        ws = mem_idx.last_stats()
+        assert o[2].tolist() == want[2].tolist() and o[0].tolist() == want[0].tolist(), (q.shape[0], ef)
+        assert o[1].view(np.uint32).tolist() == want[1].view(np.uint32).tolist()
+        for f in ("expansions", "edges", "evals", "pushes"):
+            assert st[f] == ws[f], (f, q.shape[0], ef)
 
 
 def test_concurrent_recompute_calls_that_fail_get_their_own_errors(orc):
