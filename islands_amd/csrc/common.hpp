@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
