@@ -386,8 +386,13 @@ class LeannIndex:
         p = C.c_void_p()
         n = C.c_size_t()
         _check(_ffi.lib().isl_index_to_bytes(self._h, C.byref(p), C.byref(n)))
-        data = C.string_at(p, n.value)
-        _ffi.lib().isl_free_bytes(p)
+        try:
+            if n.value < (1 << 30):
+                data = C.string_at(p, n.value)
+            else:  # (string_at takes a C int: a 10M-node index serialises to 5 GB)
+                data = bytes((C.c_char * n.value).from_address(p.value))
+        finally:
+            _ffi.lib().isl_free_bytes(p)
         return data
 
     def close(self) -> None:
