@@ -207,13 +207,15 @@ def measure_traffic(args):
             "traffic_over_algorithmic": round(traffic / alg, 4) if alg else None}
 
 
-def measure_neutral(args):
-    """`neutral_workload` of the default line: this script once more, as a child, on dataset M / --graph knn /
-    1M rows with the same query batch, k, ef, steps and warm-up."""
+def measure_neutral(args, graph):
+    """`neutral_workload[_knn]` of the default line: this script once more, as a child, on 1M rows of dataset M with
+    the same query batch, k, ef, steps and warm-up; graph = "product" (the library's own isl_index_build, i.e. the
+    reference's LeannIndex::build rule: builder and search both the library's) or "knn" (exact nearest-neighbour
+    lists by the library's brute force)."""
     import subprocess
 
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--dataset", "M", "--graph", "knn", "--nodes", "1000000", "--dim", str(args.dim), "--nq", str(args.nq),
+           "--dataset", "M", "--graph", graph, "--nodes", "1000000", "--dim", str(args.dim), "--nq", str(args.nq),
            "--k", str(args.k), "--ef", str(args.ef), "--no-traffic", "--no-cpu-baseline", "--no-host-path", "--no-neutral-side"]
     t0 = time.time()
     pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
@@ -225,7 +227,7 @@ def measure_neutral(args):
             "roofline_frac": r["roofline"]["frac"], "per_query": r["config"]["per_query"],
             "workload": r["config"]["workload"], "graph_build_s": r["config"]["graph_build_s"],
             "child_run_s": round(time.time() - t0, 1),
-            "command": "python bench.py --dataset M --graph knn --nodes 1000000 (same nq, k, ef, steps, warm-up)"}
+            "command": f"python bench.py --dataset M --graph {graph} --nodes 1000000 (same nq, k, ef, steps, warm-up)"}
 
 
 def launch_ranks(n: int) -> int:
@@ -785,12 +787,15 @@ def main():
             and args.graph == "harness" and not args.rehearse_shard and args.row_dtype == "f32"):
         # The headline's rows and graph come from one harness (a tree of clusters and a graph built from that
         # tree).  Beside it, in the same line: rows nobody designed a graph for and the graph anybody would build
-        # first -- exact nearest-neighbour lists by the library's brute force -- at 1M rows (the 10M build takes
-        # five minutes: profiles/r04_bench_M_knn_10m.json).  A child process; this one has long finished timing.
-        try:
-            result["neutral_workload"] = measure_neutral(args)
-        except Exception as e:
-            result["neutral_workload"] = {"value": None, "note": f"not measured: {e!r}"[:300]}
+        # first -- the library's own builder (isl_index_build: the reference's LeannIndex::build rule), and exact
+        # nearest-neighbour lists by the library's brute force -- at 1M rows (at 10M the builds take two and five
+        # minutes: profiles/r04_bench_M_product_10m.json, r04_bench_M_knn_10m.json).  Child processes; this one has
+        # long finished timing.
+        for key, graph in (("neutral_workload", "product"), ("neutral_workload_knn", "knn")):
+            try:
+                result[key] = measure_neutral(args, graph)
+            except Exception as e:
+                result[key] = {"value": None, "note": f"not measured: {e!r}"[:300]}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
