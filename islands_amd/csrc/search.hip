@@ -59,13 +59,13 @@ FastGeom fast_geometry(uint32_t ef, uint32_t d, uint32_t qbytes = 4, uint32_t vh
   // measured on the latter rows (1M x 768, 20 steps, profiles/r04_bench_M_knn_1m_hbits{11,12,13}.json)
   // 2048 entries 558 k queries/s, 4096 entries 686 k (12 -> 7 waves per CU and still +23 %), 8192 entries 602 k.
   // The table need not be a power of two (hslot_cap): it takes what the average query needs, in steps of 512
-  // entries and at most twice the default, and then whatever else fits beside the same number of waves per CU.
+  // entries and at most four times the default, and then whatever else fits beside the same number of waves per CU.
   static const bool no_hint = getenv("ISL_NO_VISITED_HINT") != nullptr;  // A/B switch for measurements
   static const int hcap_env = [] { const char* e = getenv("ISL_HCAP"); return e ? atoi(e) : 0; }();  // experiments only
   if (vhint && !no_hint && hbits_env == 0) {
     const uint64_t need = ((uint64_t)vhint * 8 + 6) / 7;
     if (need > hcap) {
-      const uint64_t most = (uint64_t)2 << hbits;
+      const uint64_t most = (uint64_t)4 << hbits;  // (2 x until the densest graph of DESIGN section 4: 4096 entries 357 k, 5696 420 k queries/s)
       uint64_t want = std::min<uint64_t>((need + 511) / 512 * 512, most);
       auto lds_of = [&](uint64_t cap) { return (cap * 4 + rest + 511) / 512 * 512; };  // (LDS is handed out in 512-byte granules)
       auto room = [&](size_t waves) -> uint64_t {  // the largest table that leaves `waves` waves per CU
